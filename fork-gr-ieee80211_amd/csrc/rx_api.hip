@@ -1,0 +1,391 @@
+// C-ABI entry points of libgr80211_rx.so (see include/gr80211_rx.h).
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+
+#include "rx_kernels.h"
+
+using namespace gr80211;
+
+namespace {
+
+struct Buf {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+
+}  // namespace
+
+struct gr80211_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    // workspaces (grown on demand, never shrunk)
+    Buf desc, ddesc, info, chan1, chan2, llr, slot_frame, groups, dec, bitsw, totals_d;
+    SchedTotals *totals_h = nullptr;  // pinned
+    bool profiling = false;
+    hipEvent_t ev[7] = {};
+    float ms[6] = {};
+};
+
+namespace {
+
+Tables g_tables;
+std::once_flag g_tables_once;
+bool g_uploaded[64] = {};
+std::mutex g_upload_mutex;
+
+const Tables &tables()
+{
+    std::call_once(g_tables_once, [] { build_tables(g_tables); });
+    return g_tables;
+}
+
+int fail(gr80211_ctx *c, int code, const char *what, hipError_t e = hipSuccess)
+{
+    if (c) {
+        c->err = what;
+        if (e != hipSuccess) {
+            c->err += ": ";
+            c->err += hipGetErrorString(e);
+        }
+    }
+    return code;
+}
+
+#define HIP_TRY(c, expr)                                                    \
+    do {                                                                    \
+        hipError_t e__ = (expr);                                            \
+        if (e__ != hipSuccess) return fail((c), GR80211_ERR_HIP, #expr, e__); \
+    } while (0)
+
+int ensure(gr80211_ctx *c, Buf &b, size_t bytes)
+{
+    if (bytes <= b.cap) return GR80211_OK;
+    // grow with headroom so steady-state batches of similar size never reallocate
+    size_t want = bytes + bytes / 8 + 4096;
+    if (b.p) {
+        hipError_t e = hipFree(b.p);
+        b.p = nullptr;
+        b.cap = 0;
+        if (e != hipSuccess) return fail(c, GR80211_ERR_HIP, "hipFree", e);
+    }
+    hipError_t e = hipMalloc(&b.p, want);
+    if (e != hipSuccess) {
+        b.p = nullptr;
+        return fail(c, GR80211_ERR_NOMEM, "hipMalloc workspace", e);
+    }
+    b.cap = want;
+    return GR80211_OK;
+}
+
+void release(Buf &b)
+{
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr;
+    b.cap = 0;
+}
+
+hipStream_t pick(gr80211_ctx *c, void *stream) { return stream ? (hipStream_t)stream : c->stream; }
+
+void mark(gr80211_ctx *c, int i, hipStream_t s)
+{
+    if (c->profiling) (void)hipEventRecord(c->ev[i], s);
+}
+
+int finish_timing(gr80211_ctx *c, hipStream_t s)
+{
+    if (!c->profiling) return GR80211_OK;
+    HIP_TRY(c, hipStreamSynchronize(s));
+    for (int i = 0; i < 5; i++) {
+        float v = 0.0f;
+        if (hipEventElapsedTime(&v, c->ev[i], c->ev[i + 1]) != hipSuccess) v = 0.0f;
+        c->ms[i] = v;
+    }
+    float v = 0.0f;
+    if (hipEventElapsedTime(&v, c->ev[0], c->ev[5]) != hipSuccess) v = 0.0f;
+    c->ms[5] = v;
+    return GR80211_OK;
+}
+
+// Shared tail: schedule -> (demod) -> viterbi -> traceback.
+int run_decode_stages(gr80211_ctx *c, hipStream_t s, int n, bool from_iq, const void *d_iq0, const void *d_iq1,
+                      const gr80211_frame_desc *d_desc, const float *d_llr_in, uint8_t *d_out, int out_stride,
+                      int32_t *d_out_len, int32_t *d_n_pdu, uint8_t *d_bits, int bits_stride, bool decode,
+                      const float **llr_used, uint64_t *llr_floats)
+{
+    const int slot_cap = n + 4 * 64 + 64;
+    const int group_cap = slot_cap / 64 + 1;
+    int rc;
+    if ((rc = ensure(c, c->slot_frame, (size_t)slot_cap * sizeof(int32_t)))) return rc;
+    if ((rc = ensure(c, c->groups, (size_t)group_cap * sizeof(GroupInfo)))) return rc;
+    if ((rc = ensure(c, c->totals_d, sizeof(SchedTotals)))) return rc;
+    gr80211_frame_info *info = (gr80211_frame_info *)c->info.p;
+
+    launch_schedule(info, n, from_iq ? 1 : 0, (int32_t *)c->slot_frame.p, slot_cap, (GroupInfo *)c->groups.p,
+                    group_cap, (SchedTotals *)c->totals_d.p, s);
+    mark(c, 2, s);
+    HIP_TRY(c, hipMemcpyAsync(c->totals_h, c->totals_d.p, sizeof(SchedTotals), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    const SchedTotals tot = *c->totals_h;
+    if (tot.n_groups < 0) return fail(c, GR80211_ERR_ARG, "scheduler capacity exceeded");
+
+    const float *llr = d_llr_in;
+    if (from_iq) {
+        if ((rc = ensure(c, c->llr, (size_t)(tot.llr_floats + 64) * sizeof(float)))) return rc;
+        launch_demod(d_iq0, d_iq1, d_desc, n, info, c->chan1.p, c->chan2.p, (float *)c->llr.p, s);
+        llr = (const float *)c->llr.p;
+    }
+    if (llr_used) *llr_used = llr;
+    if (llr_floats) *llr_floats = tot.llr_floats;
+    mark(c, 3, s);
+    if (decode) {
+        launch_clear_outputs(d_out_len, d_n_pdu, n, s);
+        if (tot.n_groups > 0) {
+            if ((rc = ensure(c, c->dec, (size_t)(tot.dec_words + 128) * sizeof(uint32_t)))) return rc;
+            if ((rc = ensure(c, c->bitsw, (size_t)(tot.bits_words + 64) * sizeof(uint32_t)))) return rc;
+            launch_viterbi(llr, info, (const int32_t *)c->slot_frame.p, (const GroupInfo *)c->groups.p, tot.n_groups,
+                           (uint32_t *)c->dec.p, s);
+            mark(c, 4, s);
+            launch_traceback((const uint32_t *)c->dec.p, info, (const int32_t *)c->slot_frame.p,
+                             (const GroupInfo *)c->groups.p, tot.n_groups, (uint32_t *)c->bitsw.p, d_out, out_stride,
+                             d_out_len, d_n_pdu, d_bits, bits_stride, s);
+        } else {
+            mark(c, 4, s);
+        }
+    } else {
+        mark(c, 4, s);
+    }
+    mark(c, 5, s);
+    HIP_TRY(c, hipGetLastError());
+    return GR80211_OK;
+}
+
+int stage_desc(gr80211_ctx *c, hipStream_t s, const void *desc, size_t bytes, unsigned flags, Buf &dst, const void **out)
+{
+    if (flags & GR80211_FLAG_DESC_ON_DEVICE) {
+        *out = desc;
+        return GR80211_OK;
+    }
+    int rc = ensure(c, dst, bytes);
+    if (rc) return rc;
+    HIP_TRY(c, hipMemcpyAsync(dst.p, desc, bytes, hipMemcpyHostToDevice, s));
+    *out = dst.p;
+    return GR80211_OK;
+}
+
+int front_end(gr80211_ctx *c, hipStream_t s, const void *d_iq0, const void *d_iq1, uint64_t arena_len,
+              const gr80211_frame_desc *desc, int n, unsigned flags, const gr80211_frame_desc **d_desc)
+{
+    int rc;
+    const void *dd = nullptr;
+    if ((rc = stage_desc(c, s, desc, (size_t)n * sizeof(gr80211_frame_desc), flags, c->desc, &dd))) return rc;
+    if ((rc = ensure(c, c->info, (size_t)n * sizeof(gr80211_frame_info)))) return rc;
+    if ((rc = ensure(c, c->chan1, (size_t)n * 64 * 8))) return rc;
+    if (d_iq1 && (rc = ensure(c, c->chan2, (size_t)n * 520 * 8))) return rc;
+    mark(c, 0, s);
+    launch_preamble(d_iq0, d_iq1, arena_len, (const gr80211_frame_desc *)dd, n, (gr80211_frame_info *)c->info.p,
+                    c->chan1.p, c->chan2.p, s);
+    mark(c, 1, s);
+    *d_desc = (const gr80211_frame_desc *)dd;
+    return GR80211_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *gr80211_version(void) { return "gr80211_rx 0.1 (gfx950)"; }
+
+uint32_t gr80211_table_checksum(void) { return tables_checksum(tables()); }
+
+int gr80211_create(gr80211_ctx **out, int device)
+{
+    if (!out) return GR80211_ERR_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return GR80211_ERR_HIP;
+    if (device < 0 || device >= ndev || device >= 64) return GR80211_ERR_ARG;
+    if (hipSetDevice(device) != hipSuccess) return GR80211_ERR_HIP;
+    gr80211_ctx *c = new gr80211_ctx();
+    c->device = device;
+    {
+        std::lock_guard<std::mutex> lk(g_upload_mutex);
+        if (!g_uploaded[device]) {
+            if (upload_tables(tables()) != 0) {
+                delete c;
+                return GR80211_ERR_HIP;
+            }
+            g_uploaded[device] = true;
+        }
+    }
+    if (hipStreamCreate(&c->stream) != hipSuccess) {
+        delete c;
+        return GR80211_ERR_HIP;
+    }
+    if (hipHostMalloc((void **)&c->totals_h, sizeof(SchedTotals)) != hipSuccess) {
+        (void)hipStreamDestroy(c->stream);
+        delete c;
+        return GR80211_ERR_NOMEM;
+    }
+    for (auto &e : c->ev)
+        if (hipEventCreate(&e) != hipSuccess) {
+            gr80211_destroy(c);
+            return GR80211_ERR_HIP;
+        }
+    *out = c;
+    return GR80211_OK;
+}
+
+void gr80211_destroy(gr80211_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (Buf *b : {&c->desc, &c->ddesc, &c->info, &c->chan1, &c->chan2, &c->llr, &c->slot_frame, &c->groups, &c->dec,
+                   &c->bitsw, &c->totals_d})
+        release(*b);
+    if (c->totals_h) (void)hipHostFree(c->totals_h);
+    for (auto &e : c->ev)
+        if (e) (void)hipEventDestroy(e);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char *gr80211_last_error(gr80211_ctx *c) { return c ? c->err.c_str() : "null context"; }
+
+int gr80211_sync(gr80211_ctx *c, void *stream)
+{
+    if (!c) return GR80211_ERR_ARG;
+    HIP_TRY(c, hipStreamSynchronize(pick(c, stream)));
+    return GR80211_OK;
+}
+
+int gr80211_rx_batch(gr80211_ctx *c, const void *d_iq0, const void *d_iq1, uint64_t arena_len,
+                     const gr80211_frame_desc *desc, int n, unsigned flags, uint8_t *d_out, int out_stride,
+                     int32_t *d_out_len, int32_t *d_n_pdu, gr80211_frame_info *d_info, void *stream)
+{
+    if (!c) return GR80211_ERR_ARG;
+    if (!d_iq0 || !desc || n < 0 || !d_out || !d_out_len || !d_n_pdu || out_stride < 8)
+        return fail(c, GR80211_ERR_ARG, "gr80211_rx_batch: bad argument");
+    if (n > (1 << 20)) return fail(c, GR80211_ERR_ARG, "gr80211_rx_batch: at most 1048576 frames per call");
+    if (n == 0) return GR80211_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = pick(c, stream);
+    const gr80211_frame_desc *dd = nullptr;
+    int rc = front_end(c, s, d_iq0, d_iq1, arena_len, desc, n, flags, &dd);
+    if (rc) return rc;
+    rc = run_decode_stages(c, s, n, true, d_iq0, d_iq1, dd, nullptr, d_out, out_stride, d_out_len, d_n_pdu, nullptr, 0,
+                           true, nullptr, nullptr);
+    if (rc) return rc;
+    if (d_info)
+        HIP_TRY(c, hipMemcpyAsync(d_info, c->info.p, (size_t)n * sizeof(gr80211_frame_info), hipMemcpyDeviceToDevice, s));
+    return finish_timing(c, s);
+}
+
+int gr80211_demod_batch(gr80211_ctx *c, const void *d_iq0, const void *d_iq1, uint64_t arena_len,
+                        const gr80211_frame_desc *desc, int n, unsigned flags, gr80211_frame_info *d_info,
+                        const float **d_llr, uint64_t *llr_floats, void *stream)
+{
+    if (!c) return GR80211_ERR_ARG;
+    if (!d_iq0 || !desc || n < 0 || !d_llr) return fail(c, GR80211_ERR_ARG, "gr80211_demod_batch: bad argument");
+    if (n > (1 << 20)) return fail(c, GR80211_ERR_ARG, "gr80211_demod_batch: at most 1048576 frames per call");
+    *d_llr = nullptr;
+    if (llr_floats) *llr_floats = 0;
+    if (n == 0) return GR80211_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = pick(c, stream);
+    const gr80211_frame_desc *dd = nullptr;
+    int rc = front_end(c, s, d_iq0, d_iq1, arena_len, desc, n, flags, &dd);
+    if (rc) return rc;
+    rc = run_decode_stages(c, s, n, true, d_iq0, d_iq1, dd, nullptr, nullptr, 0, nullptr, nullptr, nullptr, 0, false,
+                           d_llr, llr_floats);
+    if (rc) return rc;
+    if (d_info)
+        HIP_TRY(c, hipMemcpyAsync(d_info, c->info.p, (size_t)n * sizeof(gr80211_frame_info), hipMemcpyDeviceToDevice, s));
+    return finish_timing(c, s);
+}
+
+int gr80211_decode_batch(gr80211_ctx *c, const float *d_llr, uint64_t llr_floats, const gr80211_dec_desc *desc, int n,
+                         unsigned flags, uint8_t *d_out, int out_stride, int32_t *d_out_len, int32_t *d_n_pdu,
+                         uint8_t *d_bits, int bits_stride, void *stream)
+{
+    if (!c) return GR80211_ERR_ARG;
+    if (!d_llr || !desc || n < 0 || !d_out || !d_out_len || !d_n_pdu || out_stride < 8)
+        return fail(c, GR80211_ERR_ARG, "gr80211_decode_batch: bad argument");
+    if (d_bits && (bits_stride < 4 || (bits_stride & 3)))
+        return fail(c, GR80211_ERR_ARG, "gr80211_decode_batch: bits_stride must be a multiple of 4");
+    if (n > (1 << 20)) return fail(c, GR80211_ERR_ARG, "gr80211_decode_batch: at most 1048576 frames per call");
+    if (n == 0) return GR80211_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = pick(c, stream);
+    // descriptors must be validated against the LLR arena on the host when they are host-resident
+    if (!(flags & GR80211_FLAG_DESC_ON_DEVICE)) {
+        for (int i = 0; i < n; i++) {
+            if (desc[i].llr_off < 0 || desc[i].n_llr < 0 ||
+                (uint64_t)desc[i].llr_off + (uint64_t)desc[i].n_llr > llr_floats)
+                return fail(c, GR80211_ERR_ARG, "gr80211_decode_batch: descriptor outside the LLR arena");
+        }
+    }
+    int rc;
+    const void *dd = nullptr;
+    if ((rc = stage_desc(c, s, desc, (size_t)n * sizeof(gr80211_dec_desc), flags, c->ddesc, &dd))) return rc;
+    if ((rc = ensure(c, c->info, (size_t)n * sizeof(gr80211_frame_info)))) return rc;
+    mark(c, 0, s);
+    launch_desc_to_info((const gr80211_dec_desc *)dd, n, (gr80211_frame_info *)c->info.p, s);
+    mark(c, 1, s);
+    rc = run_decode_stages(c, s, n, false, nullptr, nullptr, nullptr, d_llr, d_out, out_stride, d_out_len, d_n_pdu,
+                           d_bits, bits_stride, true, nullptr, nullptr);
+    if (rc) return rc;
+    return finish_timing(c, s);
+}
+
+void *gr80211_dev_alloc(gr80211_ctx *c, size_t bytes)
+{
+    if (!c) return nullptr;
+    if (hipSetDevice(c->device) != hipSuccess) return nullptr;
+    void *p = nullptr;
+    if (hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) return nullptr;
+    return p;
+}
+
+void gr80211_dev_free(gr80211_ctx *c, void *p)
+{
+    if (c && p) (void)hipFree(p);
+}
+
+int gr80211_copy_h2d(gr80211_ctx *c, void *d_dst, const void *h_src, size_t bytes, void *stream)
+{
+    if (!c) return GR80211_ERR_ARG;
+    hipStream_t s = pick(c, stream);
+    HIP_TRY(c, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    return GR80211_OK;
+}
+
+int gr80211_copy_d2h(gr80211_ctx *c, void *h_dst, const void *d_src, size_t bytes, void *stream)
+{
+    if (!c) return GR80211_ERR_ARG;
+    hipStream_t s = pick(c, stream);
+    HIP_TRY(c, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    return GR80211_OK;
+}
+
+int gr80211_set_profiling(gr80211_ctx *c, int on)
+{
+    if (!c) return GR80211_ERR_ARG;
+    c->profiling = on != 0;
+    return GR80211_OK;
+}
+
+int gr80211_last_timing(gr80211_ctx *c, float *ms, int n)
+{
+    if (!c || !ms) return GR80211_ERR_ARG;
+    for (int i = 0; i < n && i < 6; i++) ms[i] = c->ms[i];
+    return GR80211_OK;
+}
+
+}  // extern "C"

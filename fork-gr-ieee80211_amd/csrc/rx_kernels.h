@@ -1,0 +1,49 @@
+// Kernel launchers of the RX hot path (internal to the library).
+#pragma once
+
+#include "rx_common.h"
+
+namespace gr80211 {
+
+// One group = 64 frames decoded by one wavefront (one frame per lane), all of one code rate.
+struct GroupInfo {
+    int32_t cr;       // code rate of every frame in the group
+    int32_t steps;    // trellis steps run (max over lanes, rounded up to whole chunks)
+    int32_t nchunks;  // LLR tile refills
+    int32_t words;    // 32-bit words of decoded bits per lane
+    uint64_t dec_off; // offset of the group's survivor words in the decision arena (uint32 units)
+    uint64_t bits_off;// offset of the group's decoded-bit words in the bit arena (uint32 units)
+};
+
+// Totals the host needs to size the arenas (copied back once per batch).
+struct SchedTotals {
+    uint64_t llr_floats;
+    uint64_t dec_words;
+    uint64_t bits_words;
+    int32_t n_groups;
+    int32_t n_valid;
+};
+
+constexpr int SCHED_NB = 513;  // trellis-length bins of 64 steps
+
+// steps per LLR tile for each code rate (whole puncture periods)
+__host__ __device__ constexpr int chunk_steps(int cr) { return cr == CR_12 ? 32 : cr == CR_23 ? 40 : cr == CR_34 ? 48 : 50; }
+
+int upload_tables(const Tables &t);
+
+void launch_preamble(const void *iq0, const void *iq1, uint64_t arena_len, const gr80211_frame_desc *desc,
+                     int n, gr80211_frame_info *info, void *chan1, void *chan2, hipStream_t s);
+void launch_desc_to_info(const gr80211_dec_desc *desc, int n, gr80211_frame_info *info, hipStream_t s);
+void launch_schedule(gr80211_frame_info *info, int n, int assign_llr, int32_t *slot_frame, int slot_cap,
+                     GroupInfo *groups, int group_cap, SchedTotals *totals, hipStream_t s);
+void launch_demod(const void *iq0, const void *iq1, const gr80211_frame_desc *desc, int n,
+                  const gr80211_frame_info *info, const void *chan1, const void *chan2, float *llr,
+                  hipStream_t s);
+void launch_viterbi(const float *llr, const gr80211_frame_info *info, const int32_t *slot_frame,
+                    const GroupInfo *groups, int n_groups, uint32_t *dec, hipStream_t s);
+void launch_traceback(const uint32_t *dec, const gr80211_frame_info *info, const int32_t *slot_frame,
+                      const GroupInfo *groups, int n_groups, uint32_t *bitsw, uint8_t *out, int out_stride,
+                      int32_t *out_len, int32_t *n_pdu, uint8_t *bits_out, int bits_stride, hipStream_t s);
+void launch_clear_outputs(int32_t *out_len, int32_t *n_pdu, int n, hipStream_t s);
+
+}  // namespace gr80211

@@ -1,0 +1,1261 @@
+// HIP kernels of the 802.11 OFDM RX hot path for MI355X (gfx950, wave64).
+//
+//   k_preamble   one wavefront per frame: CFO-derotated L-LTF/L-SIG FFTs, LS channel estimate,
+//                L-SIG / HT-SIG / VHT-SIG-A / VHT-SIG-B soft decoding (lane = trellis state),
+//                HT/VHT channel estimate incl. the 2x2 Gram inverse.
+//   k_schedule   buckets frames by code rate and trellis length into groups of 64 (decoder lanes).
+//   k_demod      one wavefront per OFDM symbol: FFT-64 by lane shuffles, one-tap or 2x2 ZF
+//                equalisation, pilot phase tracking, QAM soft demap, deinterleave / stream deparse
+//                folded into the store address.
+//   k_viterbi    one wavefront per group, lane = frame: 64-state add-compare-select fully in
+//                registers, depuncturing folded into the per-rate unrolled step sequence,
+//                LLRs staged (transposed) through LDS, survivor bits streamed to HBM.
+//   k_traceback  lane = frame: full-frame traceback, descrambling, (A-)MPDU assembly, FCS.
+//
+// Built with -ffp-contract=off: the decoder's path metrics must be the plain float32 sums the
+// reference forms (lib/decode_impl.cc:231-258), and the demodulator follows the reference's
+// operation order so that soft bits agree to rounding.
+#include <utility>
+
+#include "rx_kernels.h"
+
+namespace gr80211 {
+
+__constant__ Tables c_tab;
+
+int upload_tables(const Tables &t)
+{
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(c_tab), &t, sizeof(Tables));
+}
+
+// =========================================================================================
+// wave-level building blocks
+// =========================================================================================
+
+// 64-point forward DFT across the lanes of one wavefront (radix-2 decimation in frequency).
+// Lane l enters with x[l] and leaves with X[brev6(l)].
+__device__ __forceinline__ c32 wave_fft64(c32 x, int lane)
+{
+#pragma unroll
+    for (int s = 0; s < 6; s++) {
+        const int half = 32 >> s;
+        c32 o = mk(__shfl_xor(x.x, half), __shfl_xor(x.y, half));
+        const bool up = (lane & half) != 0;
+        c32 lo = up ? o : x;
+        c32 hi = up ? x : o;
+        c32 sum = cadd(lo, hi), dif = csub(lo, hi);
+        if (s < 5) {
+            const int k = (lane & (half - 1)) << s;
+            dif = cmul(dif, mk(c_tab.tw_re[k], c_tab.tw_im[k]));
+        }
+        x = up ? dif : sum;
+    }
+    return x;
+}
+
+constexpr int brev6c(int v)
+{
+    int r = 0;
+    for (int b = 0; b < 6; b++) r |= ((v >> b) & 1) << (5 - b);
+    return r;
+}
+constexpr int LN7 = brev6c(7), LN21 = brev6c(21), LN43 = brev6c(43), LN57 = brev6c(57);
+
+__device__ __forceinline__ bool is_pilot_bin(int b) { return b == 7 || b == 21 || b == 43 || b == 57; }
+
+// Sample k of the stream `demod` sees: the samples after L-SIG, CFO-derotated by
+// exp(j*(k+224)*rad) (lib/signal_impl.cc:172-173).  Only nvalid samples are forwarded.
+__device__ __forceinline__ c32 load_samp(const c32 *in, int k, int nvalid, float rad)
+{
+    if (k >= nvalid) return mk(0.0f, 0.0f);
+    c32 v = in[224 + k];
+    if (rad != 0.0f) {
+        float sn, cs;
+        sincosf((float)(k + 224) * rad, &sn, &cs);
+        v = cmul(v, mk(cs, sn));
+    }
+    return v;
+}
+
+// Rate-1/2 64-state soft Viterbi over <= 48 steps with one trellis state per lane
+// (svSigDecoder::decode, lib/cloud80211phy.cc:2001-2088).  llr, masks and bits live in LDS.
+__device__ void wave_sig_viterbi(const float *llr, int T, unsigned long long *masks, uint8_t *bits, int lane)
+{
+    const int j = lane & 31, b = lane >> 5, p0 = 2 * j, p1 = 2 * j + 1;
+    const int o0 = sv_out(p0, b), o1 = sv_out(p1, b);
+    float m = lane == 0 ? 0.0f : NEG_INIT;
+    __syncthreads();
+    for (int t = 0; t < T; t++) {
+        const float t0 = llr[2 * t], t1 = llr[2 * t + 1];
+        const float t01 = t1 + t0;
+        const float m0 = __shfl(m, p0), m1 = __shfl(m, p1);
+        const float bm0 = o0 == 0 ? 0.0f : o0 == 1 ? t1 : o0 == 2 ? t0 : t01;
+        const float bm1 = o1 == 0 ? 0.0f : o1 == 1 ? t1 : o1 == 2 ? t0 : t01;
+        const float a0 = m0 + bm0, a1 = m1 + bm1;
+        const bool g = a1 > a0;  // ties keep the even predecessor, as the reference's strict '>' does
+        m = g ? a1 : a0;
+        const unsigned long long mk64 = __ballot(g);
+        if (lane == 0) masks[t] = mk64;
+    }
+    __syncthreads();
+    if (lane == 0) {
+        int s = 0;
+        for (int t = T - 1; t >= 0; t--) {
+            bits[t] = (uint8_t)(s >> 5);
+            const int d = (int)((masks[t] >> s) & 1ull);
+            s = ((s & 31) << 1) | d;
+        }
+    }
+    __syncthreads();
+}
+
+// ---- SIG field checks and parsers (run by lane 0 on bits in LDS) -------------------------
+struct ModS {
+    int format, ampdu, nSym, nSymSamp, nSD, nSS, nLTF, mcs, len, mod, cr, nBPSCS, nDBPS, nCBPS, nCBPSS;
+};
+
+__device__ unsigned crc8_run(const uint8_t *in, int n)
+{
+    unsigned c = 0xff;
+    for (int i = 0; i < n; i++) {
+        c <<= 1;
+        if (c & 0x100) c = (c + 1) ^ 0x06;
+        if (in[i]) c ^= 0x07;
+    }
+    return c;
+}
+__device__ bool crc8_check(const uint8_t *in, int n, const uint8_t *crc)
+{
+    unsigned c = crc8_run(in, n);
+    for (int i = 0; i < 8; i++)
+        if (crc[i]) c ^= 1u << (7 - i);
+    return (c & 0xff) == 0xff;
+}
+
+// lib/cloud80211phy.cc:650-728
+__device__ bool check_legacy(const uint8_t *b, int *mcs, int *len, int *ndbps)
+{
+    if (!b[3]) return false;
+    if (b[4]) return false;
+    unsigned sum = 0;
+    for (int i = 0; i < 17; i++) sum += b[i];
+    if ((sum & 1) ^ b[17]) return false;
+    int rate = 0;
+    for (int i = 0; i < 4; i++) rate |= b[i] << i;
+    switch (rate) {
+    case 11: *mcs = 0; *ndbps = 24; break;
+    case 15: *mcs = 1; *ndbps = 36; break;
+    case 10: *mcs = 2; *ndbps = 48; break;
+    case 14: *mcs = 3; *ndbps = 72; break;
+    case 9: *mcs = 4; *ndbps = 96; break;
+    case 13: *mcs = 5; *ndbps = 144; break;
+    case 8: *mcs = 6; *ndbps = 192; break;
+    case 12: *mcs = 7; *ndbps = 216; break;
+    default: *mcs = 0; *ndbps = 24; break;
+    }
+    int l = 0;
+    for (int i = 0; i < 12; i++) l |= b[i + 5] << i;
+    *len = l;
+    return !(l > 4095 || l < 14);
+}
+// lib/cloud80211phy.cc:730-751
+__device__ bool check_ht(const uint8_t *b)
+{
+    if (b[26] != 1) return false;
+    if (!crc8_check(b, 34, &b[34])) return false;
+    if (b[5] + b[6] + b[7] + b[28] + b[29] + b[30] + b[32] + b[33]) return false;
+    return true;
+}
+// lib/cloud80211phy.cc:753-771
+__device__ bool check_vhta(const uint8_t *b)
+{
+    if (b[2] != 1 || b[23] != 1 || b[33] != 1) return false;
+    if (!crc8_check(b, 34, &b[34])) return false;
+    if (b[0] + b[1]) return false;
+    return true;
+}
+__device__ void set_ndbps(ModS *m)
+{
+    switch (m->cr) {
+    case CR_12: m->nDBPS = m->nCBPS / 2; break;
+    case CR_23: m->nDBPS = (m->nCBPS * 2) / 3; break;
+    case CR_34: m->nDBPS = (m->nCBPS * 3) / 4; break;
+    default: m->nDBPS = (m->nCBPS * 5) / 6; break;
+    }
+}
+__device__ int ltf_count(int nss) { return nss == 1 ? 1 : nss == 2 ? 2 : 4; }
+
+// lib/cloud80211phy.cc:773-850
+__device__ void parse_legacy(int mcs, int len, ModS *m)
+{
+    const int mod[8] = {QAM_BPSK, QAM_BPSK, QAM_QPSK, QAM_QPSK, QAM_16, QAM_16, QAM_64, QAM_64};
+    const int cr[8] = {CR_12, CR_34, CR_12, CR_34, CR_12, CR_34, CR_23, CR_34};
+    const int ndbps[8] = {24, 36, 48, 72, 96, 144, 192, 216};
+    const int nbp[8] = {1, 1, 2, 2, 4, 4, 6, 6};
+    m->mcs = mcs; m->mod = mod[mcs]; m->cr = cr[mcs]; m->nDBPS = ndbps[mcs];
+    m->nBPSCS = nbp[mcs]; m->nCBPS = 48 * nbp[mcs];
+    m->len = len; m->nCBPSS = m->nCBPS; m->nSD = 48; m->nSS = 1; m->nLTF = 0;
+    m->format = GR80211_F_L; m->nSymSamp = 80;
+    m->nSym = (len * 8 + 22) / m->nDBPS + (((len * 8 + 22) % m->nDBPS) != 0);
+    m->ampdu = 0;
+}
+// HT MCS%8 and VHT MCS 0..7 share one modulation / code-rate ladder.
+__device__ void set_rate_ladder(int r, ModS *m)
+{
+    const int mod[10] = {QAM_BPSK, QAM_QPSK, QAM_QPSK, QAM_16, QAM_16, QAM_64, QAM_64, QAM_64, QAM_256, QAM_256};
+    const int nbp[10] = {1, 2, 2, 4, 4, 6, 6, 6, 8, 8};
+    const int cr[10] = {CR_12, CR_12, CR_34, CR_12, CR_34, CR_23, CR_34, CR_56, CR_34, CR_56};
+    m->mod = mod[r]; m->nBPSCS = nbp[r]; m->cr = cr[r];
+}
+// lib/cloud80211phy.cc:852-998
+__device__ void parse_ht(const uint8_t *b, ModS *m)
+{
+    int mcs = 0, len = 0;
+    for (int i = 0; i < 7; i++) mcs |= b[i] << i;
+    for (int i = 0; i < 16; i++) len |= b[i + 8] << i;
+    m->format = GR80211_F_HT;
+    m->nSymSamp = b[31] ? 72 : 80;
+    m->ampdu = b[27] ? 1 : 0;
+    m->mcs = mcs;
+    set_rate_ladder(mcs % 8, m);
+    m->len = len;
+    m->nSS = mcs / 8 + 1;
+    m->nSD = 52;
+    m->nCBPSS = m->nBPSCS * 52;
+    m->nCBPS = m->nCBPSS * m->nSS;
+    set_ndbps(m);
+    m->nLTF = ltf_count(m->nSS);
+    m->nSym = (len * 8 + 22) / m->nDBPS + (((len * 8 + 22) % m->nDBPS) != 0);
+}
+// lib/cloud80211phy.cc:1090-1178 with modParserVht (1225-1323); false = outside this build's
+// scope (MU group id, MCS 10..15 for which the reference keeps stale state).
+__device__ bool parse_vhta(const uint8_t *b, ModS *m)
+{
+    int gid = 0, nsts = 0, mcs = 0;
+    for (int i = 0; i < 6; i++) gid |= b[i + 4] << i;
+    m->format = GR80211_F_VHT;
+    m->nSymSamp = b[24] ? 72 : 80;
+    m->ampdu = 1;
+    if (!(gid == 0 || gid == 63)) return false;
+    for (int i = 0; i < 3; i++) nsts |= b[i + 10] << i;
+    for (int i = 0; i < 4; i++) mcs |= b[i + 28] << i;
+    m->nSS = nsts + 1;
+    m->mcs = mcs;
+    if (mcs > 9) return false;
+    set_rate_ladder(mcs, m);
+    m->nSD = 52;
+    m->nCBPSS = m->nBPSCS * 52;
+    m->nCBPS = m->nCBPSS * m->nSS;
+    set_ndbps(m);
+    m->nLTF = ltf_count(m->nSS);
+    return true;
+}
+// lib/cloud80211phy.cc:1180-1223, single-user branch
+__device__ void parse_vhtb(const uint8_t *b, ModS *m)
+{
+    if ((b[17] + b[18] + b[19]) == 3) {
+        int l = 0;
+        for (int i = 0; i < 17; i++) l |= b[i] << i;
+        m->len = l * 4;
+        m->nSym = (m->len * 8 + 16 + 6) / m->nDBPS + (((m->len * 8 + 16 + 6) % m->nDBPS) != 0);
+    } else {
+        unsigned pat = 0;
+        for (int i = 0; i < 20; i++) pat |= (unsigned)b[i] << i;
+        if (pat == 0x422E0u) { m->len = 0; m->nSym = 0; }
+        else { m->len = -1; m->nSym = -1; }
+    }
+}
+
+// Two-antenna zero forcing for one tone: x = (H^H H)^-1 H^H y (lib/demod2_impl.cc:515-518).
+__device__ __forceinline__ void zf2(c32 F1, c32 F2, const c32 (&h)[4], const c32 (&hi)[4], c32 &s1, c32 &s2)
+{
+    const c32 t1 = cadd(cmul(F1, cconj(h[0])), cmul(F2, cconj(h[1])));
+    const c32 t2 = cadd(cmul(F1, cconj(h[2])), cmul(F2, cconj(h[3])));
+    s1 = cadd(cmul(t1, hi[0]), cmul(t2, hi[2]));
+    s2 = cadd(cmul(t1, hi[1]), cmul(t2, hi[3]));
+}
+
+// =========================================================================================
+// k_preamble
+// =========================================================================================
+constexpr int CH2 = 520;  // per-frame 2x2 channel block: H[64][4], Hinv[64][4], pilot refs [2][4]
+
+__global__ __launch_bounds__(64) void k_preamble(const c32 *__restrict__ iq0, const c32 *__restrict__ iq1,
+                                                 uint64_t arena_len, const gr80211_frame_desc *__restrict__ descs,
+                                                 int n, gr80211_frame_info *__restrict__ info,
+                                                 c32 *__restrict__ chan1, c32 *__restrict__ chan2)
+{
+    const int f = blockIdx.x;
+    if (f >= n) return;
+    const int lane = threadIdx.x;
+    const int bin = brev6(lane);
+
+    __shared__ float s_llr[2][96];
+    __shared__ unsigned long long s_mask[48];
+    __shared__ uint8_t s_bits[48];
+    __shared__ ModS s_m;
+    __shared__ int s_ctl[8];  // 0 status, 1 lsig_mcs, 2 lsig_len, 3 nsamp, 4 fmt, 5 trellis, 6 data_off
+    __shared__ float s_snr[2];
+    __shared__ double s_red[64];
+
+    const gr80211_frame_desc d = descs[f];
+    uint64_t so = d.sync_off;
+    uint64_t navail64 = d.n_avail;
+    if (so >= arena_len) { so = 0; navail64 = 0; }
+    if (so + navail64 > arena_len) navail64 = arena_len - so;
+    const int navail = (int)(navail64 > 0x7fffffffull ? 0x7fffffffull : navail64);
+    const float rad = d.rad;
+    const c32 *in0 = iq0 + so;
+    const c32 *in1 = iq1 ? iq1 + so : nullptr;
+    const bool two_ant = in1 != nullptr;
+
+    if (lane < 8) s_ctl[lane] = 0;
+    if (lane == 0) {
+        ModS z = {};
+        s_m = z;
+        s_snr[0] = 0.0f;
+        s_snr[1] = 0.0f;
+    }
+    __syncthreads();
+
+    const float ltfl = c_tab.ltf_l[bin];
+    const float ltfn = c_tab.ltf_nl[bin];
+    const bool lused = ltfl != 0.0f;
+    const bool nused = ltfn != 0.0f;
+    const int demap = c_tab.lsig_demap[bin];
+    c32 hl = mk(0.0f, 0.0f);
+    int nvalid = 0;
+    int pos = 0;
+
+    if (navail < 224) {
+        if (lane == 0) s_ctl[0] = GR80211_ST_DROP_LSIG;
+        __syncthreads();
+        goto finish;
+    }
+
+    // ---- signal: L-LTF x2 + L-SIG (lib/signal_impl.cc:108-162, lib/cloud80211phy.cc:609-627)
+    {
+        c32 x1 = in0[SHIFT + lane], x2 = in0[SHIFT + 64 + lane], xs = in0[SHIFT + 144 + lane];
+        if (rad != 0.0f) {
+            float sn, cs;
+            sincosf((lane + SHIFT) * rad, &sn, &cs);
+            x1 = cmul(x1, mk(cs, sn));
+            sincosf((lane + SHIFT + 64) * rad, &sn, &cs);
+            x2 = cmul(x2, mk(cs, sn));
+            sincosf((lane + SHIFT + 144) * rad, &sn, &cs);
+            xs = cmul(xs, mk(cs, sn));
+        }
+        const c32 S1 = wave_fft64(x1, lane), S2 = wave_fft64(x2, lane), SG = wave_fft64(xs, lane);
+        c32 e = mk(0.0f, 0.0f);
+        if (lused) {
+            hl = cdivf(cadd(S1, S2), ltfl * 2.0f);
+            e = cdiv(SG, hl);
+        }
+        const c32 e7 = shfl_c(e, LN7), e21 = shfl_c(e, LN21), e43 = shfl_c(e, LN43), e57 = shfl_c(e, LN57);
+        const c32 ps = cconj(cadd(cadd(csub(e7, e21), e43), e57));
+        const float pa = cabs32(ps);
+        if (demap >= 0) s_llr[0][demap] = cdivf(cmul(e, ps), pa).x;
+        wave_sig_viterbi(s_llr[0], 24, s_mask, s_bits, lane);
+        if (lane == 0) {
+            int mcs = 0, len = 0, ndbps = 24;
+            if (!check_legacy(s_bits, &mcs, &len, &ndbps)) {
+                s_ctl[0] = GR80211_ST_DROP_LSIG;
+            } else {
+                s_ctl[1] = mcs;
+                s_ctl[2] = len;
+                s_ctl[3] = ((len * 8 + 22 + ndbps - 1) / ndbps) * 80;
+            }
+        }
+        __syncthreads();
+        if (s_ctl[0] != GR80211_ST_OK) goto finish;
+    }
+    nvalid = s_ctl[3];
+    if (nvalid > navail - 224) nvalid = navail - 224;
+
+    // ---- format detection (lib/demod_impl.cc:106-148, lib/cloud80211phy.cc:629-648)
+    if (s_ctl[1] == 0) {
+        const c32 F1 = wave_fft64(load_samp(in0, SHIFT + lane, nvalid, rad), lane);
+        const c32 F2 = wave_fft64(load_samp(in0, 80 + SHIFT + lane, nvalid, rad), lane);
+        c32 e1 = mk(0.0f, 0.0f), e2 = mk(0.0f, 0.0f);
+        if (lused) {
+            e1 = cdiv(F1, hl);
+            e2 = cdiv(F2, hl);
+        }
+        const c32 p1 = cconj(cadd(cadd(csub(shfl_c(e1, LN7), shfl_c(e1, LN21)), shfl_c(e1, LN43)), shfl_c(e1, LN57)));
+        const c32 p2 = cconj(cadd(cadd(csub(shfl_c(e2, LN7), shfl_c(e2, LN21)), shfl_c(e2, LN43)), shfl_c(e2, LN57)));
+        const float a1 = cabs32(p1), a2 = cabs32(p2);
+        if (demap >= 0) {
+            const c32 m1 = cdivf(cmul(e1, p1), a1), m2 = cdivf(cmul(e2, p2), a2);
+            s_llr[0][demap] = m1.x;       // VHT-SIG-A: BPSK then QBPSK
+            s_llr[0][demap + 48] = m2.y;
+            s_llr[1][demap] = m1.y;       // HT-SIG: QBPSK twice
+            s_llr[1][demap + 48] = m2.y;
+        }
+        wave_sig_viterbi(s_llr[0], 48, s_mask, s_bits, lane);
+        if (lane == 0) {
+            if (check_vhta(s_bits)) {
+                s_ctl[4] = GR80211_F_VHT;
+                if (!parse_vhta(s_bits, &s_m)) s_ctl[0] = GR80211_ST_DROP_UNSUPPORTED;
+            } else {
+                s_ctl[4] = -1;
+            }
+        }
+        __syncthreads();
+        if (s_ctl[0] != GR80211_ST_OK) goto finish;
+        if (s_ctl[4] == -1) {
+            wave_sig_viterbi(s_llr[1], 48, s_mask, s_bits, lane);
+            if (lane == 0) {
+                if (check_ht(s_bits)) {
+                    s_ctl[4] = GR80211_F_HT;
+                    parse_ht(s_bits, &s_m);
+                } else {
+                    s_ctl[4] = GR80211_F_L;
+                }
+            }
+            __syncthreads();
+        }
+        if (s_ctl[4] != GR80211_F_L) pos = 160;
+    }
+
+    if (s_ctl[4] == GR80211_F_L) {
+        // lib/demod_impl.cc:207-219
+        if (lane == 0) {
+            parse_legacy(s_ctl[1], s_ctl[2], &s_m);
+            s_ctl[5] = s_m.len * 8 + 22;
+            s_ctl[6] = 0;
+        }
+        chan1[(size_t)f * 64 + bin] = hl;
+        __syncthreads();
+        goto finish;
+    }
+
+    // ---- HT / VHT: channel estimate (+ VHT-SIG-B) -----------------------------------------
+    {
+        const int fmt = s_ctl[4];
+        const int nss = s_m.nSS, nltf = s_m.nLTF;
+        if (nss > 2 || (nss == 2 && !two_ant)) {
+            if (lane == 0) s_ctl[0] = GR80211_ST_DROP_UNSUPPORTED;
+            __syncthreads();
+            goto finish;
+        }
+        const int off = pos + 80;
+        c32 h[4], hi[4];
+        c32 hn = mk(0.0f, 0.0f);
+        c32 pl1 = mk(0.0f, 0.0f), pl2 = mk(0.0f, 0.0f);  // LTF-derived pilot references (pilot lanes)
+        if (nss == 1) {
+            // lib/demod_impl.cc:380-392
+            const c32 F1 = wave_fft64(load_samp(in0, off + SHIFT + lane, nvalid, rad), lane);
+            if (nused) hn = cdivf(F1, ltfn);
+            chan1[(size_t)f * 64 + bin] = hn;
+        } else {
+            // lib/demod2_impl.cc:372-463
+            const c32 F1 = wave_fft64(load_samp(in0, off + SHIFT + lane, nvalid, rad), lane);
+            const c32 F2 = wave_fft64(load_samp(in1, off + SHIFT + lane, nvalid, rad), lane);
+            const c32 F12 = wave_fft64(load_samp(in0, off + 80 + SHIFT + lane, nvalid, rad), lane);
+            const c32 F22 = wave_fft64(load_samp(in1, off + 80 + SHIFT + lane, nvalid, rad), lane);
+            const float l2 = ltfn * 0.5f;
+            h[0] = cmulf(csub(F1, F12), l2);
+            h[1] = cmulf(csub(F2, F22), l2);
+            h[2] = cmulf(cadd(F1, F12), l2);
+            h[3] = cmulf(cadd(F2, F22), l2);
+            if (fmt == GR80211_F_VHT) {
+                const int lm = brev6((bin + 63) & 63), lp = brev6((bin + 1) & 63);
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const c32 a = shfl_c(h[q], lm), b = shfl_c(h[q], lp);
+                    if (is_pilot_bin(bin)) h[q] = cdivf(cadd(a, b), 2.0f);
+                }
+            }
+            if (nused) {
+                const c32 a = cadd(cmul(h[0], cconj(h[0])), cmul(h[1], cconj(h[1])));
+                const c32 b = cadd(cmul(h[0], cconj(h[2])), cmul(h[1], cconj(h[3])));
+                const c32 c = cadd(cmul(h[2], cconj(h[0])), cmul(h[3], cconj(h[1])));
+                const c32 dd = cadd(cmul(h[2], cconj(h[2])), cmul(h[3], cconj(h[3])));
+                const c32 adbc = cdiv(mk(1.0f, 0.0f), csub(cmul(a, dd), cmul(b, c)));
+                hi[0] = cmul(adbc, dd);
+                hi[1] = cmul(cneg(adbc), b);
+                hi[2] = cmul(cneg(adbc), c);
+                hi[3] = cmul(adbc, a);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; q++) { h[q] = mk(0.0f, 0.0f); hi[q] = mk(0.0f, 0.0f); }
+            }
+            c32 *c2 = chan2 + (size_t)f * CH2;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                c2[bin * 4 + q] = h[q];
+                c2[256 + bin * 4 + q] = hi[q];
+            }
+            if (is_pilot_bin(bin)) {
+                c32 e1, e2;
+                zf2(F1, F2, h, hi, e1, e2);
+                if (bin == 57) { e1 = cneg(e1); e2 = cneg(e2); }
+                pl1 = cconj(e1);
+                pl2 = cconj(e2);
+                const int slot = bin == 43 ? 0 : bin == 57 ? 1 : bin == 7 ? 2 : 3;
+                c2[512 + slot] = pl1;
+                c2[516 + slot] = pl2;
+            }
+        }
+
+        const int nleg = (s_ctl[2] * 8 + 22 + 23) / 24;
+        if (fmt == GR80211_F_VHT) {
+            // VHT-SIG-B (lib/demod_impl.cc:449-505, lib/demod2_impl.cc:632-758)
+            const int ob = off + nltf * 80;
+            c32 q0 = mk(0.0f, 0.0f), q1 = mk(0.0f, 0.0f);
+            const int jn = c_tab.data_idx_nl[bin];
+            float inted = 0.0f;
+            if (nss == 1) {
+                const c32 F1 = wave_fft64(load_samp(in0, ob + SHIFT + lane, nvalid, rad), lane);
+                c32 e = mk(0.0f, 0.0f);
+                if (nused) e = cdiv(F1, hn);
+                const c32 ps = cconj(cadd(cadd(csub(shfl_c(e, LN7), shfl_c(e, LN21)), shfl_c(e, LN43)), shfl_c(e, LN57)));
+                const float pa = cabs32(ps);
+                q0 = cdivf(cmul(e, ps), pa);
+                inted = q0.x;
+            } else {
+                const c32 F1 = wave_fft64(load_samp(in0, ob + SHIFT + lane, nvalid, rad), lane);
+                const c32 F2 = wave_fft64(load_samp(in1, ob + SHIFT + lane, nvalid, rad), lane);
+                c32 s1, s2;
+                zf2(F1, F2, h, hi, s1, s2);
+                const c32 u1 = cmul(s1, pl1), u2 = cmul(s2, pl2);  // meaningful on pilot lanes
+                c32 acc = shfl_c(u1, LN7);
+                acc = csub(acc, shfl_c(u1, LN21));
+                acc = cadd(acc, shfl_c(u1, LN43));
+                acc = cadd(acc, shfl_c(u1, LN57));
+                acc = cadd(acc, shfl_c(u2, LN7));
+                acc = csub(acc, shfl_c(u2, LN21));
+                acc = cadd(acc, shfl_c(u2, LN43));
+                acc = cadd(acc, shfl_c(u2, LN57));
+                const c32 ps = cconj(acc);
+                const float pa = cabs32(ps);
+                q0 = cdivf(cmul(s1, ps), pa);
+                q1 = cdivf(cmul(s2, ps), pa);
+                inted = (q0.x + q1.x) / 2.0f;
+            }
+            if (jn >= 0) s_llr[0][c_tab.deint_nl[0][jn]] = inted;
+            wave_sig_viterbi(s_llr[0], 26, s_mask, s_bits, lane);
+            // per-stream SNR from the re-encoded SIG-B (float64 accumulation as in the reference)
+            double n0 = 0.0, n1 = 0.0;
+            if (jn >= 0) {
+                const int k = c_tab.deint_nl[0][jn];  // coded bit carried by this tone
+                const int i = k >> 1;
+                int st = 0;
+                for (int m2 = 0; m2 < 7; m2++)
+                    if (i - m2 >= 0 && s_bits[i - m2]) st |= 1 << m2;
+                const int cb = (k & 1) ? parity7(st & 0117) : parity7(st & 0155);
+                const float ref = cb ? 1.0f : -1.0f;
+                const c32 r0 = mk(q0.x - ref, q0.y - 0.0f);
+                n0 = (double)(r0.x * r0.x + r0.y * r0.y);
+                if (nss == 2) {
+                    const c32 r1 = mk(q1.x - ref, q1.y - 0.0f);
+                    n1 = (double)(r1.x * r1.x + r1.y * r1.y);
+                }
+            }
+            // ordered sum over data tones 0..51 (the reference's accumulation order)
+            s_red[jn >= 0 ? jn : 52 + (lane % 12)] = n0;
+            __syncthreads();
+            if (lane == 0) {
+                double acc = 0.0;
+                for (int i = 0; i < 52; i++) acc += s_red[i];
+                s_snr[0] = (float)(log10(52.0 / acc) * 10.0);
+            }
+            __syncthreads();
+            if (nss == 2) {
+                s_red[jn >= 0 ? jn : 52 + (lane % 12)] = n1;
+                __syncthreads();
+                if (lane == 0) {
+                    double acc = 0.0;
+                    for (int i = 0; i < 52; i++) acc += s_red[i];
+                    s_snr[1] = (float)(log10(52.0 / acc) * 10.0);
+                }
+                __syncthreads();
+            }
+            if (lane == 0) {
+                parse_vhtb(s_bits, &s_m);
+                const ModS m = s_m;
+                if (m.len == 0 && m.nSym == 0) {
+                    s_ctl[0] = GR80211_ST_DROP_UNSUPPORTED;  // NDP
+                } else if (!(m.len > 0 && m.len <= 4095 && m.nSS <= 2 &&
+                             (nleg * 80) >= (m.nSym * m.nSymSamp + 160 + 80 + m.nLTF * 80 + 80))) {
+                    s_ctl[0] = GR80211_ST_DROP_LEN_CHECK;
+                } else {
+                    s_ctl[5] = m.nSym * m.nDBPS;
+                    s_ctl[6] = pos + 80 + m.nLTF * 80 + 80;
+                }
+            }
+        } else {
+            if (lane == 0) {
+                const ModS m = s_m;
+                if (!(m.len > 0 && m.len <= 4095 && m.nSS <= 2 &&
+                      (nleg * 80) >= (m.nSym * m.nSymSamp + 160 + 80 + m.nLTF * 80))) {
+                    s_ctl[0] = GR80211_ST_DROP_LEN_CHECK;
+                } else {
+                    s_ctl[5] = m.len * 8 + 22;
+                    s_ctl[6] = pos + 80 + m.nLTF * 80;
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+finish:
+    if (lane == 0) {
+        gr80211_frame_info fi;
+        const ModS m = s_m;
+        fi.status = s_ctl[0];
+        fi.lsig_mcs = s_ctl[1];
+        fi.lsig_len = s_ctl[2];
+        fi.nsamp = s_ctl[3];
+        fi.format = m.format; fi.mcs = m.mcs; fi.len = m.len; fi.cr = m.cr; fi.ampdu = m.ampdu;
+        fi.trellis = s_ctl[5];
+        fi.total = s_ctl[0] == GR80211_ST_OK ? m.nSym * m.nCBPS : 0;
+        fi.nSym = m.nSym; fi.nSS = m.nSS; fi.nLTF = m.nLTF; fi.nCBPS = m.nCBPS; fi.nDBPS = m.nDBPS;
+        fi.nBPSCS = m.nBPSCS; fi.mod = m.mod;
+        fi.sssnr0 = s_snr[0]; fi.sssnr1 = s_snr[1];
+        fi.cfo_hz = rad * 3183098.8618379068f;  // rad * 20e6 / 2pi (lib/signal_impl.cc:136)
+        fi.snr = d.snr; fi.rssi = d.rssi;
+        fi.slot = -1;
+        fi.llr_off = 0;
+        fi.data_off = s_ctl[6];
+        fi.nSymSamp = m.nSymSamp;
+        info[f] = fi;
+    }
+}
+
+// =========================================================================================
+// k_desc_to_info: decode-only entry, tags -> frame records
+// =========================================================================================
+__global__ void k_desc_to_info(const gr80211_dec_desc *__restrict__ desc, int n, gr80211_frame_info *__restrict__ info)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const gr80211_dec_desc d = desc[i];
+    gr80211_frame_info fi = {};
+    fi.status = GR80211_ST_OK;
+    fi.format = d.format; fi.len = d.len; fi.cr = d.cr; fi.mcs = d.mcs; fi.ampdu = d.ampdu;
+    fi.trellis = d.trellis; fi.total = d.n_llr; fi.llr_off = d.llr_off; fi.slot = -1;
+    if (d.cr < 0 || d.cr > 3 || d.n_llr < 0 || d.llr_off < 0) fi.status = GR80211_ST_DROP_UNSUPPORTED;
+    info[i] = fi;
+}
+
+// =========================================================================================
+// k_schedule (single workgroup)
+// =========================================================================================
+__device__ __forceinline__ uint32_t round64(uint32_t v) { return (v + 63u) & ~63u; }
+
+__global__ __launch_bounds__(1024) void k_schedule(gr80211_frame_info *__restrict__ info, int n, int assign_llr,
+                                                   int32_t *__restrict__ slot_frame, int slot_cap,
+                                                   GroupInfo *__restrict__ groups, int group_cap,
+                                                   SchedTotals *__restrict__ totals)
+{
+    __shared__ uint32_t hist[4 * SCHED_NB];
+    __shared__ uint32_t crstart[5];
+    __shared__ unsigned long long part[1024];
+    __shared__ unsigned long long part2[1024];
+    __shared__ int s_nvalid;
+    const int tid = threadIdx.x;
+    for (int k = tid; k < 4 * SCHED_NB; k += 1024) hist[k] = 0;
+    if (tid == 0) s_nvalid = 0;
+    __syncthreads();
+
+    const int per = (n + 1023) / 1024;
+    const int i0 = tid * per < n ? tid * per : n;
+    const int i1 = i0 + per < n ? i0 + per : n;
+
+    // pass 1: decode admission (lib/decode_impl.cc:93), histogram, LLR space per thread
+    unsigned long long sum = 0;
+    int nv = 0;
+    for (int i = i0; i < i1; i++) {
+        int st = info[i].status;
+        const int tr = info[i].trellis, len = info[i].len, cr = info[i].cr;
+        if (st == GR80211_ST_OK && (len > GR80211_MAX_PSDU || tr > GR80211_MAX_TRELLIS || tr <= 0 || cr < 0 || cr > 3)) {
+            st = GR80211_ST_DROP_DECODE_LIMIT;
+            info[i].status = st;
+        }
+        if (st == GR80211_ST_OK) {
+            atomicAdd(&hist[cr * SCHED_NB + tr / 64], 1u);
+            nv++;
+        }
+        if (st == GR80211_ST_OK || st == GR80211_ST_DROP_DECODE_LIMIT) sum += (unsigned long long)info[i].total;
+    }
+    part[tid] = sum;
+    if (nv) atomicAdd(&s_nvalid, nv);
+    __syncthreads();
+    if (tid == 0) {
+        unsigned long long run = 0;
+        for (int k = 0; k < 1024; k++) { const unsigned long long v = part[k]; part[k] = run; run += v; }
+        totals->llr_floats = assign_llr ? run : 0;
+        uint32_t p = 0;
+        for (int cr = 0; cr < 4; cr++) {
+            p = round64(p);
+            crstart[cr] = p;
+            for (int b = 0; b < SCHED_NB; b++) { const uint32_t c = hist[cr * SCHED_NB + b]; hist[cr * SCHED_NB + b] = p; p += c; }
+        }
+        crstart[4] = round64(p);
+    }
+    __syncthreads();
+    const int n_slots = (int)crstart[4];
+    const int n_groups = n_slots / 64;
+    if (n_slots > slot_cap || n_groups > group_cap) {  // host sized these from n; cannot happen
+        if (tid == 0) { totals->n_groups = -1; totals->n_valid = 0; totals->dec_words = 0; totals->bits_words = 0; }
+        return;
+    }
+    if (assign_llr) {
+        unsigned long long run = part[tid];
+        for (int i = i0; i < i1; i++) {
+            const int st = info[i].status;
+            if (st == GR80211_ST_OK || st == GR80211_ST_DROP_DECODE_LIMIT) {
+                info[i].llr_off = (int64_t)run;
+                run += (unsigned long long)info[i].total;
+            }
+        }
+    }
+    for (int s = tid; s < n_slots; s += 1024) slot_frame[s] = -1;
+    for (int g = tid; g < n_groups; g += 1024) {
+        const uint32_t s0 = (uint32_t)g * 64u;
+        GroupInfo gi;
+        gi.cr = s0 >= crstart[3] ? 3 : s0 >= crstart[2] ? 2 : s0 >= crstart[1] ? 1 : 0;
+        gi.steps = 0; gi.nchunks = 0; gi.words = 0; gi.dec_off = 0; gi.bits_off = 0;
+        groups[g] = gi;
+    }
+    __syncthreads();
+    // pass 2: slots
+    for (int i = i0; i < i1; i++) {
+        if (info[i].status == GR80211_ST_OK) {
+            const int tr = info[i].trellis;
+            const uint32_t slot = atomicAdd(&hist[info[i].cr * SCHED_NB + tr / 64], 1u);
+            info[i].slot = (int32_t)slot;
+            slot_frame[slot] = i;
+            atomicMax(&groups[slot / 64].steps, tr);
+        } else {
+            info[i].slot = -1;
+        }
+    }
+    __syncthreads();
+    const int gper = (n_groups + 1023) / 1024;
+    const int g0 = tid * gper < n_groups ? tid * gper : n_groups;
+    const int g1 = g0 + gper < n_groups ? g0 + gper : n_groups;
+    unsigned long long dsum = 0, bsum = 0;
+    for (int g = g0; g < g1; g++) {
+        const int cs = chunk_steps(groups[g].cr);
+        const int nch = (groups[g].steps + cs - 1) / cs;
+        const int steps = nch * cs;
+        groups[g].nchunks = nch;
+        groups[g].steps = steps;
+        groups[g].words = (steps + 31) / 32;
+        dsum += (unsigned long long)steps * 128ull;
+        bsum += (unsigned long long)((steps + 31) / 32) * 64ull;
+    }
+    part[tid] = dsum;
+    part2[tid] = bsum;
+    __syncthreads();
+    if (tid == 0) {
+        unsigned long long r1 = 0, r2 = 0;
+        for (int k = 0; k < 1024; k++) {
+            const unsigned long long v1 = part[k], v2 = part2[k];
+            part[k] = r1; part2[k] = r2;
+            r1 += v1; r2 += v2;
+        }
+        totals->dec_words = r1;
+        totals->bits_words = r2;
+        totals->n_groups = n_groups;
+        totals->n_valid = s_nvalid;
+    }
+    __syncthreads();
+    unsigned long long r1 = part[tid], r2 = part2[tid];
+    for (int g = g0; g < g1; g++) {
+        groups[g].dec_off = r1;
+        groups[g].bits_off = r2;
+        r1 += (unsigned long long)groups[g].steps * 128ull;
+        r2 += (unsigned long long)groups[g].words * 64ull;
+    }
+}
+
+// =========================================================================================
+// k_demod: one workgroup (4 waves) per frame, each wave strides over OFDM symbols
+// =========================================================================================
+// Max-log soft demap of one axis after constellation scaling (lib/cloud80211phy.cc:2090-2148).
+__device__ __forceinline__ void axis_llr(float v, int nb, float *o)
+{
+    o[0] = v;
+    if (nb >= 2) {
+        const float edge = nb == 2 ? 2.0f : nb == 3 ? 4.0f : 8.0f;
+        const float l1 = edge - fabsf(v);
+        o[1] = l1;
+        if (nb >= 3) {
+            const float l2 = edge * 0.5f - fabsf(l1);
+            o[2] = l2;
+            if (nb >= 4) o[3] = 2.0f - fabsf(l2);
+        }
+    }
+}
+
+__device__ __forceinline__ float qam_scale(int mod)
+{
+    return mod == QAM_QPSK ? 1.4142135623730951f : mod == QAM_16 ? 3.1622776601683795f
+         : mod == QAM_64 ? 6.48074069840786f : mod == QAM_256 ? 13.038404810405298f : 1.0f;
+}
+
+__global__ __launch_bounds__(256) void k_demod(const c32 *__restrict__ iq0, const c32 *__restrict__ iq1,
+                                               const gr80211_frame_desc *__restrict__ descs, int n,
+                                               const gr80211_frame_info *__restrict__ info,
+                                               const c32 *__restrict__ chan1, const c32 *__restrict__ chan2,
+                                               float *__restrict__ llr)
+{
+    const int f = blockIdx.x;
+    if (f >= n) return;
+    const int st = info[f].status;
+    if (!(st == GR80211_ST_OK || st == GR80211_ST_DROP_DECODE_LIMIT)) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int bin = brev6(lane);
+    const gr80211_frame_info fi = info[f];
+    const gr80211_frame_desc d = descs[f];
+    const c32 *in0 = iq0 + d.sync_off;
+    const c32 *in1 = iq1 ? iq1 + d.sync_off : nullptr;
+    const float rad = d.rad;
+    int nvalid = fi.nsamp;
+    if (nvalid > (int)d.n_avail - 224) nvalid = (int)d.n_avail - 224;
+
+    const int fmt = fi.format, nss = fi.nSS, nb = fi.nBPSCS, ncbps = fi.nCBPS;
+    const bool legacy = fmt == GR80211_F_L;
+    const bool used = legacy ? (c_tab.ltf_l[bin] != 0.0f) : (c_tab.ltf_nl[bin] != 0.0f);
+    const bool pil = is_pilot_bin(bin);
+    const int jd = legacy ? c_tab.data_idx_l[bin] : c_tab.data_idx_nl[bin];
+    const int pslot = bin == 43 ? 0 : bin == 57 ? 1 : bin == 7 ? 2 : 3;
+    const int didx = nb == 1 ? 0 : nb == 2 ? 1 : nb == 4 ? 2 : nb == 6 ? 3 : 4;
+    const float scale = qam_scale(fi.mod);
+    const int nax = nb == 1 ? 1 : nb / 2;  // bits per axis (BPSK: one bit, I axis only)
+    float *out = llr + fi.llr_off;
+    const int pp0 = legacy ? 1 : fmt == GR80211_F_HT ? 3 : 4;
+
+    if (nss == 1) {
+        const c32 h = chan1[(size_t)f * 64 + bin];
+        const int16_t *map = legacy ? c_tab.deint_l[didx] : c_tab.deint_nl[didx];
+        const float base[4] = {1.0f, 1.0f, 1.0f, -1.0f};  // PILOT_L = PILOT_HT_1 = PILOT_VHT
+        for (int sym = wave; sym < fi.nSym; sym += 4) {
+            const int off = fi.data_off + sym * fi.nSymSamp;
+            const c32 F = wave_fft64(load_samp(in0, off + SHIFT + lane, nvalid, rad), lane);
+            c32 e = mk(0.0f, 0.0f);
+            if (used) e = cdiv(F, h);
+            // pilot term of this lane's tone: sig * pilot * polarity (lib/demod_impl.cc:426-430)
+            const float pp = c_tab.pilot_p[(pp0 + sym) % 127];
+            const float pv = legacy ? base[pslot] : base[(pslot + sym) & 3];
+            const c32 u = cmulf(cmulf(e, pv), pp);
+            const c32 ps = cconj(cadd(cadd(cadd(shfl_c(u, LN7), shfl_c(u, LN21)), shfl_c(u, LN43)), shfl_c(u, LN57)));
+            const float pa = cabs32(ps);
+            c32 q = cdivf(cmul(e, ps), pa);
+            if (jd >= 0) {
+                if (fi.mod != QAM_BPSK) q = cmulf(q, scale);
+                float li[4], lq[4];
+                axis_llr(q.x, nax, li);
+                axis_llr(q.y, nax, lq);
+                float *o = out + (size_t)sym * ncbps;
+                if (nb == 1) {
+                    o[map[jd]] = li[0];
+                } else {
+                    for (int b = 0; b < nax; b++) {
+                        o[map[jd * nb + b]] = li[b];
+                        o[map[jd * nb + nax + b]] = lq[b];
+                    }
+                }
+            }
+        }
+    } else {
+        // two spatial streams on two antennas (lib/demod2_impl.cc:504-550, 586-628)
+        const c32 *c2 = chan2 + (size_t)f * CH2;
+        c32 h[4], hi[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) { h[q] = c2[bin * 4 + q]; hi[q] = c2[256 + bin * 4 + q]; }
+        const c32 pl1 = pil ? c2[512 + pslot] : mk(0.0f, 0.0f);
+        const c32 pl2 = pil ? c2[516 + pslot] : mk(0.0f, 0.0f);
+        const bool vht = fmt == GR80211_F_VHT;
+        const float b1[4] = {1.0f, 1.0f, 1.0f, -1.0f};    // PILOT_VHT
+        const float bh1[4] = {1.0f, 1.0f, -1.0f, -1.0f};  // PILOT_HT_2_1
+        const float bh2[4] = {1.0f, -1.0f, -1.0f, 1.0f};  // PILOT_HT_2_2
+        const int16_t *map1 = c_tab.deint_nl[didx];
+        const int16_t *map2 = c_tab.deint_nl2[didx];
+        const int sblk = nb / 2 > 1 ? nb / 2 : 1;  // stream parser block
+        for (int sym = wave; sym < fi.nSym; sym += 4) {
+            const int off = fi.data_off + sym * fi.nSymSamp;
+            const c32 F1 = wave_fft64(load_samp(in0, off + SHIFT + lane, nvalid, rad), lane);
+            const c32 F2 = wave_fft64(load_samp(in1, off + SHIFT + lane, nvalid, rad), lane);
+            c32 s1 = mk(0.0f, 0.0f), s2 = mk(0.0f, 0.0f);
+            if (used) zf2(F1, F2, h, hi, s1, s2);
+            const float pp = c_tab.pilot_p[(pp0 + sym) % 127];
+            const int pr = (pslot + sym) & 3;
+            const float pv1 = vht ? b1[pr] : bh1[pr];
+            const float pv2 = vht ? b1[pr] : bh2[pr];
+            const c32 u1 = cmul(cmulf(cmulf(s1, pv1), pp), pl1);
+            const c32 u2 = cmul(cmulf(cmulf(s2, pv2), pp), pl2);
+            c32 acc = shfl_c(u1, LN7);
+            acc = cadd(acc, shfl_c(u1, LN21));
+            acc = cadd(acc, shfl_c(u1, LN43));
+            acc = cadd(acc, shfl_c(u1, LN57));
+            acc = cadd(acc, shfl_c(u2, LN7));
+            acc = cadd(acc, shfl_c(u2, LN21));
+            acc = cadd(acc, shfl_c(u2, LN43));
+            acc = cadd(acc, shfl_c(u2, LN57));
+            const c32 ps = cconj(acc);
+            const float pa = cabs32(ps);
+            if (jd >= 0) {
+                float *o = out + (size_t)sym * ncbps;
+#pragma unroll
+                for (int ss = 0; ss < 2; ss++) {
+                    c32 q = cdivf(cmul(ss ? s2 : s1, ps), pa);
+                    if (fi.mod != QAM_BPSK) q = cmulf(q, scale);
+                    float li[4], lq[4];
+                    axis_llr(q.x, nax, li);
+                    axis_llr(q.y, nax, lq);
+                    const int16_t *map = ss ? map2 : map1;
+                    const int nbits = nb == 1 ? 1 : nb;
+                    for (int b = 0; b < nbits; b++) {
+                        const float v = nb == 1 ? li[0] : (b < nax ? li[b] : lq[b - nax]);
+                        const int k = map[jd * nb + b];  // position in this stream's deinterleaved block
+                        // stream de-parser: blocks of sblk bits alternate (lib/cloud80211phy.cc:2442-2451)
+                        o[(k / sblk) * 2 * sblk + ss * sblk + (k % sblk)] = v;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// =========================================================================================
+// k_viterbi: lane = frame, 64 states in registers
+// =========================================================================================
+template <int KIND, int OP>
+__device__ __forceinline__ float add_tab(float m, float t0, float t1, float t01)
+{
+    // KIND 0: both soft bits present; 1: second erased (t1 = 0); 2: first erased (t0 = 0).
+    // Adding the table entry 0.0f leaves a metric unchanged, so those adds are dropped.
+    if constexpr (KIND == 0) {
+        if constexpr (OP == 0) return m;
+        else if constexpr (OP == 1) return m + t1;
+        else if constexpr (OP == 2) return m + t0;
+        else return m + t01;
+    } else if constexpr (KIND == 1) {
+        if constexpr (OP == 0 || OP == 1) return m;
+        else return m + t0;
+    } else {
+        if constexpr (OP == 0 || OP == 2) return m;
+        else return m + t1;
+    }
+}
+
+template <int KIND, int N>
+__device__ __forceinline__ void acs_one(const float (&m)[64], float (&o)[64], float t0, float t1, float t01, uint32_t &dw)
+{
+    constexpr int j = N & 31, b = N >> 5, p0 = 2 * j, p1 = 2 * j + 1;
+    constexpr int o0 = sv_out(p0, b), o1 = sv_out(p1, b);
+    const float a0 = add_tab<KIND, o0>(m[p0], t0, t1, t01);
+    const float a1 = add_tab<KIND, o1>(m[p1], t0, t1, t01);
+    const bool g = a1 > a0;  // strict: ties keep the even predecessor (lib/decode_impl.cc:248-258)
+    o[N] = g ? a1 : a0;
+    dw = (dw << 1) | (g ? 1u : 0u);
+}
+
+template <int KIND, int BASE, int... N>
+__device__ __forceinline__ void acs_range(const float (&m)[64], float (&o)[64], float t0, float t1, float t01,
+                                          uint32_t &dw, std::integer_sequence<int, N...>)
+{
+    (acs_one<KIND, BASE + N>(m, o, t0, t1, t01, dw), ...);
+}
+
+// One trellis step for 64 frames.  Survivor bit of state n lands in bit 31-(n&31) of word n>>5.
+template <int KIND>
+__device__ __forceinline__ void acs_step(const float (&m)[64], float (&o)[64], float t0, float t1, uint32_t *dec)
+{
+    const float t01 = t1 + t0;
+    uint32_t d0 = 0, d1 = 0;
+    acs_range<KIND, 0>(m, o, t0, t1, t01, d0, std::make_integer_sequence<int, 32>{});
+    acs_range<KIND, 32>(m, o, t0, t1, t01, d1, std::make_integer_sequence<int, 32>{});
+    dec[0] = d0;
+    dec[64] = d1;
+}
+
+template <int CR> struct Rate;
+template <> struct Rate<CR_12> { static constexpr int P = 1, COLS = 2, NPER = 32; };
+template <> struct Rate<CR_23> { static constexpr int P = 2, COLS = 3, NPER = 20; };
+template <> struct Rate<CR_34> { static constexpr int P = 3, COLS = 4, NPER = 16; };
+template <> struct Rate<CR_56> { static constexpr int P = 5, COLS = 6, NPER = 10; };
+
+// One puncture period (lib/cloud80211phy.cc:1857-1860): starts in A; ends in B when P is odd.
+template <int CR>
+__device__ __forceinline__ void period(float (&A)[64], float (&B)[64], const float *c, uint32_t *dec)
+{
+    if constexpr (CR == CR_12) {
+        acs_step<0>(A, B, c[0], c[1], dec);
+    } else if constexpr (CR == CR_23) {
+        acs_step<0>(A, B, c[0], c[1], dec);
+        acs_step<1>(B, A, c[2], 0.0f, dec + 128);
+    } else if constexpr (CR == CR_34) {
+        acs_step<0>(A, B, c[0], c[1], dec);
+        acs_step<1>(B, A, c[2], 0.0f, dec + 128);
+        acs_step<2>(A, B, 0.0f, c[3], dec + 256);
+    } else {
+        acs_step<0>(A, B, c[0], c[1], dec);
+        acs_step<1>(B, A, c[2], 0.0f, dec + 128);
+        acs_step<2>(A, B, 0.0f, c[3], dec + 256);
+        acs_step<1>(B, A, c[4], 0.0f, dec + 384);
+        acs_step<2>(A, B, 0.0f, c[5], dec + 512);
+    }
+}
+
+constexpr int TILE_STRIDE = 65;
+
+template <int CR>
+__device__ __forceinline__ void viterbi_group(const float *__restrict__ llr, const unsigned long long *rowbase,
+                                              const int *rown, int nchunks, uint32_t *__restrict__ dec,
+                                              float *tile, int lane)
+{
+    constexpr int P = Rate<CR>::P, COLS = Rate<CR>::COLS, NPER = Rate<CR>::NPER;
+    constexpr int CH = COLS * NPER;    // LLR columns per tile
+    constexpr int STEPS = P * NPER;    // trellis steps per tile
+    float A[64], B[64];
+#pragma unroll
+    for (int i = 0; i < 64; i++) A[i] = i == 0 ? 0.0f : NEG_INIT;
+    const float *row = tile + lane * TILE_STRIDE;
+    for (int ch = 0; ch < nchunks; ch++) {
+        __syncthreads();
+        const int c0 = ch * CH + lane;
+#pragma unroll 8
+        for (int r = 0; r < 64; r++) {
+            float v = 0.0f;
+            if (lane < CH && c0 < rown[r]) v = llr[rowbase[r] + (unsigned long long)c0];
+            tile[r * TILE_STRIDE + lane] = v;
+        }
+        __syncthreads();
+        uint32_t *dp = dec + (size_t)ch * STEPS * 128 + lane;
+#pragma unroll 1
+        for (int pp = 0; pp < NPER; pp += 2) {
+            period<CR>(A, B, row + pp * COLS, dp + (size_t)pp * P * 128);
+            if constexpr (P & 1) period<CR>(B, A, row + (pp + 1) * COLS, dp + (size_t)(pp + 1) * P * 128);
+            else period<CR>(A, B, row + (pp + 1) * COLS, dp + (size_t)(pp + 1) * P * 128);
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) void k_viterbi(const float *__restrict__ llr, const gr80211_frame_info *__restrict__ info,
+                                                const int32_t *__restrict__ slot_frame,
+                                                const GroupInfo *__restrict__ groups, int n_groups,
+                                                uint32_t *__restrict__ dec)
+{
+    const int g = blockIdx.x;
+    if (g >= n_groups) return;
+    const int lane = threadIdx.x;
+    __shared__ float tile[64 * TILE_STRIDE];
+    __shared__ unsigned long long rowbase[64];
+    __shared__ int rown[64];
+    const GroupInfo gi = groups[g];
+    const int fr = slot_frame[g * 64 + lane];
+    rowbase[lane] = fr >= 0 ? (unsigned long long)info[fr].llr_off : 0ull;
+    rown[lane] = fr >= 0 ? info[fr].total : 0;
+    uint32_t *d = dec + gi.dec_off;
+    switch (gi.cr) {
+    case CR_12: viterbi_group<CR_12>(llr, rowbase, rown, gi.nchunks, d, tile, lane); break;
+    case CR_23: viterbi_group<CR_23>(llr, rowbase, rown, gi.nchunks, d, tile, lane); break;
+    case CR_34: viterbi_group<CR_34>(llr, rowbase, rown, gi.nchunks, d, tile, lane); break;
+    default: viterbi_group<CR_56>(llr, rowbase, rown, gi.nchunks, d, tile, lane); break;
+    }
+}
+
+// =========================================================================================
+// k_traceback: traceback + descramble + packet assembly + FCS, lane = frame
+// =========================================================================================
+__device__ __forceinline__ uint32_t crc_byte(uint32_t c, uint32_t byte, const uint32_t *tab)
+{
+    return tab[(c ^ byte) & 0xff] ^ (c >> 8);
+}
+
+__global__ __launch_bounds__(64) void k_traceback(const uint32_t *__restrict__ dec, const gr80211_frame_info *__restrict__ info,
+                                                  const int32_t *__restrict__ slot_frame,
+                                                  const GroupInfo *__restrict__ groups, int n_groups,
+                                                  uint32_t *__restrict__ bitsw, uint8_t *__restrict__ out, int out_stride,
+                                                  int32_t *__restrict__ out_len, int32_t *__restrict__ n_pdu,
+                                                  uint8_t *__restrict__ bits_out, int bits_stride)
+{
+    const int g = blockIdx.x;
+    if (g >= n_groups) return;
+    const int lane = threadIdx.x;
+    __shared__ uint32_t s_crc[256];
+    for (int i = lane; i < 256; i += 64) s_crc[i] = c_tab.crc[i];
+    __syncthreads();
+
+    const GroupInfo gi = groups[g];
+    const int fr = slot_frame[g * 64 + lane];
+    const int T = fr >= 0 ? info[fr].trellis : 0;
+    const uint32_t *d = dec + gi.dec_off + lane;
+    uint32_t *bw = bitsw + gi.bits_off + lane;
+
+    // ---- traceback from state 0 at step T (lib/decode_impl.cc:282-302)
+    {
+        int s = 0;
+        uint32_t acc = 0;
+        for (int t = gi.steps - 1; t >= 0; t--) {
+            const uint32_t w0 = d[(size_t)t * 128], w1 = d[(size_t)t * 128 + 64];
+            if (t == T - 1) s = 0;
+            acc |= (uint32_t)(s >> 5) << (t & 31);  // decoded bit t = newest bit of the state after step t
+            const uint32_t w = (s & 32) ? w1 : w0;
+            const int dbit = (int)((w >> (31 - (s & 31))) & 1u);
+            s = ((s & 31) << 1) | dbit;
+            if ((t & 31) == 0) {
+                bw[(size_t)(t >> 5) * 64] = acc;
+                acc = 0;
+            }
+        }
+    }
+    if (fr < 0) return;
+    const gr80211_frame_info fi = info[fr];
+    const int nwords = gi.words;
+
+    // ---- descrambler sequence (lib/decode_impl.cc:304-323).  With S[0..6] = the first seven
+    // decoded bits and S[i] = S[i-7]^S[i-4], the data bits are decoded[i]^S[i] (zero for i<7).
+    uint32_t W0 = 0, W1 = 0;
+    {
+        const uint32_t first = bw[0];
+        uint32_t hist = 0;  // bit k = S[i-1-k]
+        for (int i = 0; i < 64; i++) {
+            uint32_t sbit;
+            if (i < 7) sbit = (first >> i) & 1u;
+            else sbit = ((hist >> 6) ^ (hist >> 3)) & 1u;
+            hist = (hist << 1) | sbit;
+            if (i < 32) W0 |= sbit << i;
+            else W1 |= sbit << (i - 32);
+        }
+    }
+
+    // ---- packet assembly (lib/decode_impl.cc:325-520).  PSDU dword q = data bits 16+32q .. 16+32q+31.
+    uint8_t *o = out + (size_t)fr * out_stride;
+    uint8_t *bo = bits_out ? bits_out + (size_t)fr * bits_stride : nullptr;
+    const bool vht = fi.format == GR80211_F_VHT;
+    const int T32 = (T + 31) / 32;
+    int wpos = 0;      // bytes committed to the output slot
+    int npdu = 0;
+    // MPDU being collected
+    int mlen = -1;     // -1: expecting a delimiter (VHT) ; >= 0 collecting
+    int mgot = 0, mpad = 0;
+    uint32_t crc = 0xFFFFFFFFu;
+    int tl = 0;        // delimiter length, OR-accumulated as the reference does (lib/decode_impl.cc:336)
+    int eof = 0;
+    int procd = 16;    // bits consumed, as tmpBitsProcd
+    bool done = false;
+    if (!vht) {
+        if (fi.ampdu) done = true;  // HT A-MPDU: nothing published (lib/decode_impl.cc:432-435)
+        mlen = fi.len; mpad = fi.len;
+    } else if (procd >= T) {
+        done = true;
+    }
+    uint32_t Sprev2 = W0, Sprev1 = W1;  // scrambler words k-2, k-1 relative to the next one to make
+    uint32_t Dcur = bw[0] ^ W0;         // descrambled word 0
+    if (bo && bits_stride >= 4) *(uint32_t *)(bo) = Dcur;
+    for (int k = 1; k <= T32 && k <= nwords; k++) {
+        // descrambled word k
+        uint32_t Sk;
+        if (k == 1) Sk = W1;
+        else { Sk = Sprev1 ^ ((Sprev2 >> 8) | (Sprev1 << 24)); Sprev2 = Sprev1; Sprev1 = Sk; }
+        const uint32_t raw = k < nwords ? bw[(size_t)k * 64] : 0u;
+        const uint32_t Dnext = raw ^ Sk;
+        if (bo && k < T32 && (k + 1) * 4 <= bits_stride) *(uint32_t *)(bo + (size_t)k * 4) = Dnext;
+        const uint32_t psdu = (Dcur >> 16) | (Dnext << 16);  // PSDU dword q = k-1
+        Dcur = Dnext;
+        if (done) continue;
+        if (mlen < 0) {
+            // A-MPDU delimiter: bit0 EOF, bits2-3 len[13:12], bits4-15 len[11:0] (lib/decode_impl.cc:339-358)
+            procd += 32;
+            if (procd > T) { done = true; continue; }
+            eof = (int)(psdu & 1u);
+            tl |= (int)((psdu >> 2) & 1u) << 12;
+            tl |= (int)((psdu >> 3) & 1u) << 13;
+            tl |= (int)((psdu >> 4) & 0xfffu);
+            const int padded = (tl / 4 + ((tl % 4) != 0)) * 4;
+            procd += padded * 8;
+            if (procd > T) { done = true; continue; }
+            mlen = tl; mpad = padded; mgot = 0; crc = 0xFFFFFFFFu;
+            if (mpad == 0) {  // zero-length subframe: CRC of nothing never matches; move on
+                mlen = -1;
+                if (eof) done = true;
+            }
+            continue;
+        }
+        // payload dword
+        const bool store = (mlen <= GR80211_MAX_PSDU) && (wpos + 3 + mlen + 1 <= out_stride);
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            if (mgot + b < mlen) {
+                const uint32_t by = (psdu >> (8 * b)) & 0xffu;
+                crc = crc_byte(crc, by, s_crc);
+                if (store) o[wpos + 3 + mgot + b] = (uint8_t)by;
+            }
+        }
+        mgot += 4;
+        if (mgot >= mpad) {
+            if (store && (crc ^ 0xFFFFFFFFu) == 558161692u) {  // lib/decode_impl.cc:374,453
+                o[wpos] = (uint8_t)fi.format;
+                o[wpos + 1] = (uint8_t)(mlen % 256);
+                o[wpos + 2] = (uint8_t)(mlen / 256);
+                o[wpos + 3 + mlen] = (uint8_t)fi.mcs;
+                wpos += mlen + 4;
+                npdu++;
+            }
+            if (vht) {
+                mlen = -1;
+                if (eof) done = true;
+            } else {
+                done = true;
+            }
+        }
+    }
+    out_len[fr] = wpos;
+    n_pdu[fr] = npdu;
+}
+
+__global__ void k_clear_outputs(int32_t *a, int32_t *b, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { a[i] = 0; b[i] = 0; }
+}
+
+// =========================================================================================
+// launchers
+// =========================================================================================
+void launch_preamble(const void *iq0, const void *iq1, uint64_t arena_len, const gr80211_frame_desc *desc, int n,
+                     gr80211_frame_info *info, void *chan1, void *chan2, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_preamble, dim3(n), dim3(64), 0, s, (const c32 *)iq0, (const c32 *)iq1, arena_len, desc, n,
+                       info, (c32 *)chan1, (c32 *)chan2);
+}
+void launch_desc_to_info(const gr80211_dec_desc *desc, int n, gr80211_frame_info *info, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_desc_to_info, dim3((n + 255) / 256), dim3(256), 0, s, desc, n, info);
+}
+void launch_schedule(gr80211_frame_info *info, int n, int assign_llr, int32_t *slot_frame, int slot_cap,
+                     GroupInfo *groups, int group_cap, SchedTotals *totals, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_schedule, dim3(1), dim3(1024), 0, s, info, n, assign_llr, slot_frame, slot_cap, groups,
+                       group_cap, totals);
+}
+void launch_demod(const void *iq0, const void *iq1, const gr80211_frame_desc *desc, int n,
+                  const gr80211_frame_info *info, const void *chan1, const void *chan2, float *llr, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_demod, dim3(n), dim3(256), 0, s, (const c32 *)iq0, (const c32 *)iq1, desc, n, info,
+                       (const c32 *)chan1, (const c32 *)chan2, llr);
+}
+void launch_viterbi(const float *llr, const gr80211_frame_info *info, const int32_t *slot_frame,
+                    const GroupInfo *groups, int n_groups, uint32_t *dec, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_viterbi, dim3(n_groups), dim3(64), 0, s, llr, info, slot_frame, groups, n_groups, dec);
+}
+void launch_traceback(const uint32_t *dec, const gr80211_frame_info *info, const int32_t *slot_frame,
+                      const GroupInfo *groups, int n_groups, uint32_t *bitsw, uint8_t *out, int out_stride,
+                      int32_t *out_len, int32_t *n_pdu, uint8_t *bits_out, int bits_stride, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_traceback, dim3(n_groups), dim3(64), 0, s, dec, info, slot_frame, groups, n_groups, bitsw,
+                       out, out_stride, out_len, n_pdu, bits_out, bits_stride);
+}
+void launch_clear_outputs(int32_t *out_len, int32_t *n_pdu, int n, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_clear_outputs, dim3((n + 255) / 256), dim3(256), 0, s, out_len, n_pdu, n);
+}
+
+}  // namespace gr80211

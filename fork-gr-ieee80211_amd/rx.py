@@ -1,0 +1,262 @@
+"""ctypes binding of libgr80211_rx.so (the MI355X RX hot path) for tests, bench and tools.
+
+Device memory is owned by torch tensors (torch is plumbing here: allocation, streams,
+torch.distributed); every compute call goes through the C-ABI declared in
+include/gr80211_rx.h.  There is no CPU fallback: if the HIP library is missing or no GPU is
+present, construction raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgr80211_rx.so")
+
+ST_NAMES = {0: "ok", 1: "drop_lsig", 2: "drop_len_check", 3: "drop_unsupported", 4: "drop_decode_limit"}
+FLAG_DESC_ON_DEVICE = 1
+
+
+class FrameDesc(C.Structure):
+    _fields_ = [("sync_off", C.c_uint64), ("n_avail", C.c_uint32), ("rad", C.c_float),
+                ("snr", C.c_float), ("rssi", C.c_float), ("reserved", C.c_uint32 * 2)]
+
+
+class FrameInfo(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "status", "lsig_mcs", "lsig_len", "nsamp", "format", "mcs", "len", "cr", "ampdu", "trellis",
+        "total", "nSym", "nSS", "nLTF", "nCBPS", "nDBPS", "nBPSCS", "mod")] + [
+        ("sssnr0", C.c_float), ("sssnr1", C.c_float), ("cfo_hz", C.c_float), ("snr", C.c_float),
+        ("rssi", C.c_float), ("slot", C.c_int32), ("llr_off", C.c_int64), ("data_off", C.c_int32),
+        ("nSymSamp", C.c_int32)]
+
+
+class DecDesc(C.Structure):
+    _fields_ = [("llr_off", C.c_int64), ("n_llr", C.c_int32), ("format", C.c_int32), ("len", C.c_int32),
+                ("cr", C.c_int32), ("mcs", C.c_int32), ("ampdu", C.c_int32), ("trellis", C.c_int32),
+                ("reserved", C.c_int32)]
+
+
+FRAME_DESC_DTYPE = np.dtype([("sync_off", "<u8"), ("n_avail", "<u4"), ("rad", "<f4"), ("snr", "<f4"),
+                             ("rssi", "<f4"), ("reserved", "<u4", (2,))])
+FRAME_INFO_DTYPE = np.dtype(
+    [(n, "<i4") for n in ("status", "lsig_mcs", "lsig_len", "nsamp", "format", "mcs", "len", "cr", "ampdu",
+                          "trellis", "total", "nSym", "nSS", "nLTF", "nCBPS", "nDBPS", "nBPSCS", "mod")] +
+    [("sssnr0", "<f4"), ("sssnr1", "<f4"), ("cfo_hz", "<f4"), ("snr", "<f4"), ("rssi", "<f4"),
+     ("slot", "<i4"), ("llr_off", "<i8"), ("data_off", "<i4"), ("nSymSamp", "<i4")])
+DEC_DESC_DTYPE = np.dtype([("llr_off", "<i8"), ("n_llr", "<i4"), ("format", "<i4"), ("len", "<i4"),
+                           ("cr", "<i4"), ("mcs", "<i4"), ("ampdu", "<i4"), ("trellis", "<i4"),
+                           ("reserved", "<i4")])
+
+assert FRAME_DESC_DTYPE.itemsize == C.sizeof(FrameDesc) == 32
+assert FRAME_INFO_DTYPE.itemsize == C.sizeof(FrameInfo) == 112
+assert DEC_DESC_DTYPE.itemsize == C.sizeof(DecDesc) == 40
+
+EXPORTS = [
+    "gr80211_create", "gr80211_destroy", "gr80211_last_error", "gr80211_sync", "gr80211_rx_batch",
+    "gr80211_demod_batch", "gr80211_decode_batch", "gr80211_dev_alloc", "gr80211_dev_free",
+    "gr80211_copy_h2d", "gr80211_copy_d2h", "gr80211_set_profiling", "gr80211_last_timing",
+    "gr80211_version", "gr80211_table_checksum",
+]
+
+_lib = None
+
+
+def load_library():
+    """dlopen the HIP library and declare the C-ABI signatures.  Raises if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("HIP library %s not built; run __graft_entry__.build()" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    L.gr80211_create.argtypes = [C.POINTER(vp), C.c_int]
+    L.gr80211_destroy.argtypes = [vp]
+    L.gr80211_destroy.restype = None
+    L.gr80211_last_error.argtypes = [vp]
+    L.gr80211_last_error.restype = C.c_char_p
+    L.gr80211_sync.argtypes = [vp, vp]
+    L.gr80211_rx_batch.argtypes = [vp, vp, vp, C.c_uint64, vp, C.c_int, C.c_uint, vp, C.c_int, vp, vp, vp, vp]
+    L.gr80211_demod_batch.argtypes = [vp, vp, vp, C.c_uint64, vp, C.c_int, C.c_uint, vp, C.POINTER(vp),
+                                      C.POINTER(C.c_uint64), vp]
+    L.gr80211_decode_batch.argtypes = [vp, vp, C.c_uint64, vp, C.c_int, C.c_uint, vp, C.c_int, vp, vp, vp,
+                                       C.c_int, vp]
+    L.gr80211_dev_alloc.argtypes = [vp, C.c_size_t]
+    L.gr80211_dev_alloc.restype = vp
+    L.gr80211_dev_free.argtypes = [vp, vp]
+    L.gr80211_dev_free.restype = None
+    L.gr80211_copy_h2d.argtypes = [vp, vp, vp, C.c_size_t, vp]
+    L.gr80211_copy_d2h.argtypes = [vp, vp, vp, C.c_size_t, vp]
+    L.gr80211_set_profiling.argtypes = [vp, C.c_int]
+    L.gr80211_last_timing.argtypes = [vp, C.POINTER(C.c_float), C.c_int]
+    L.gr80211_version.restype = C.c_char_p
+    L.gr80211_table_checksum.restype = C.c_uint32
+    _lib = L
+    return L
+
+
+def split_pdus(blob):
+    """Split concatenated [format][len16 LE][MPDU][mcs] messages (lib/decode_impl.cc:512-516)."""
+    out = []
+    p = 0
+    while p + 4 <= len(blob):
+        ln = blob[p + 1] | (blob[p + 2] << 8)
+        out.append(dict(format=int(blob[p]), mcs=int(blob[p + 3 + ln]), mpdu=bytes(blob[p + 3:p + 3 + ln])))
+        p += ln + 4
+    return out
+
+
+class RxContext:
+    """One GPU's RX pipeline.  Inputs/outputs are torch CUDA tensors or numpy host arrays."""
+
+    def __init__(self, device=0):
+        import torch
+        if not torch.cuda.is_available():
+            raise RuntimeError("no GPU: the RX hot path has no CPU fallback")
+        self.torch = torch
+        self.lib = load_library()
+        self.device = int(device)
+        self.dev = torch.device("cuda", self.device)
+        h = C.c_void_p()
+        rc = self.lib.gr80211_create(C.byref(h), self.device)
+        if rc != 0:
+            raise RuntimeError("gr80211_create failed: %d" % rc)
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.gr80211_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- helpers ------------------------------------------------------------------------
+    def _check(self, rc, what):
+        if rc != 0:
+            raise RuntimeError("%s failed (%d): %s" % (what, rc, self.lib.gr80211_last_error(self.h).decode()))
+
+    def _stream(self):
+        return C.c_void_p(self.torch.cuda.current_stream(self.dev).cuda_stream)
+
+    def to_device(self, a):
+        t = self.torch
+        if isinstance(a, t.Tensor):
+            return a.to(self.dev).contiguous()
+        a = np.ascontiguousarray(a)
+        if a.dtype.fields is not None:
+            return t.from_numpy(a.view(np.uint8).reshape(-1)).to(self.dev)
+        return t.from_numpy(a).to(self.dev)
+
+    def set_profiling(self, on):
+        self._check(self.lib.gr80211_set_profiling(self.h, 1 if on else 0), "set_profiling")
+
+    def last_timing(self):
+        ms = (C.c_float * 6)()
+        self._check(self.lib.gr80211_last_timing(self.h, ms, 6), "last_timing")
+        return dict(zip(("preamble", "schedule", "demod", "viterbi", "traceback", "total"), list(ms)))
+
+    def sync(self):
+        self._check(self.lib.gr80211_sync(self.h, self._stream()), "sync")
+
+    @staticmethod
+    def make_desc(sync_off, n_avail, rad=None, snr=None, rssi=None):
+        n = len(sync_off)
+        d = np.zeros(n, dtype=FRAME_DESC_DTYPE)
+        d["sync_off"] = sync_off
+        d["n_avail"] = n_avail
+        if rad is not None:
+            d["rad"] = rad
+        if snr is not None:
+            d["snr"] = snr
+        if rssi is not None:
+            d["rssi"] = rssi
+        return d
+
+    def _desc_arg(self, desc):
+        """Returns (pointer, flags, keepalive)."""
+        t = self.torch
+        if isinstance(desc, t.Tensor):
+            return C.c_void_p(desc.data_ptr()), FLAG_DESC_ON_DEVICE, desc
+        desc = np.ascontiguousarray(desc)
+        return C.c_void_p(desc.ctypes.data), 0, desc
+
+    # -- entry points -------------------------------------------------------------------
+    def rx_batch(self, iq0, iq1, desc, n_frames, out_stride=4104, want_info=True):
+        """IQ -> PDUs.  iq0/iq1: complex64 CUDA tensors (iq1 None = one antenna).
+        Returns dict of CUDA tensors out[n,out_stride] u8, out_len[n], n_pdu[n], info (bytes)."""
+        t = self.torch
+        assert iq0.is_cuda and iq0.dtype == t.complex64 and iq0.is_contiguous()
+        if iq1 is not None:
+            assert iq1.is_cuda and iq1.dtype == t.complex64 and iq1.numel() == iq0.numel()
+        out = t.empty((n_frames, out_stride), dtype=t.uint8, device=self.dev)
+        out_len = t.empty(n_frames, dtype=t.int32, device=self.dev)
+        n_pdu = t.empty(n_frames, dtype=t.int32, device=self.dev)
+        info = t.empty(n_frames * FRAME_INFO_DTYPE.itemsize, dtype=t.uint8, device=self.dev) if want_info else None
+        dp, flags, keep = self._desc_arg(desc)
+        rc = self.lib.gr80211_rx_batch(
+            self.h, C.c_void_p(iq0.data_ptr()), C.c_void_p(iq1.data_ptr()) if iq1 is not None else None,
+            iq0.numel(), dp, n_frames, flags, C.c_void_p(out.data_ptr()), out_stride,
+            C.c_void_p(out_len.data_ptr()), C.c_void_p(n_pdu.data_ptr()),
+            C.c_void_p(info.data_ptr()) if info is not None else None, self._stream())
+        self._check(rc, "gr80211_rx_batch")
+        return dict(out=out, out_len=out_len, n_pdu=n_pdu, info=info, _keep=keep)
+
+    def rx_batch_into(self, iq0, iq1, desc, n_frames, out, out_len, n_pdu, info=None):
+        """Same as rx_batch with caller-owned output tensors (no allocation in the timed region)."""
+        dp, flags, keep = self._desc_arg(desc)
+        rc = self.lib.gr80211_rx_batch(
+            self.h, C.c_void_p(iq0.data_ptr()), C.c_void_p(iq1.data_ptr()) if iq1 is not None else None,
+            iq0.numel(), dp, n_frames, flags, C.c_void_p(out.data_ptr()), out.shape[1],
+            C.c_void_p(out_len.data_ptr()), C.c_void_p(n_pdu.data_ptr()),
+            C.c_void_p(info.data_ptr()) if info is not None else None, self._stream())
+        self._check(rc, "gr80211_rx_batch")
+        return keep
+
+    def demod_batch(self, iq0, iq1, desc, n_frames):
+        """IQ -> LLRs.  Returns (info ndarray, llr ndarray on host)."""
+        t = self.torch
+        info = t.empty(n_frames * FRAME_INFO_DTYPE.itemsize, dtype=t.uint8, device=self.dev)
+        dp, flags, keep = self._desc_arg(desc)
+        llr_ptr = C.c_void_p()
+        nfl = C.c_uint64(0)
+        rc = self.lib.gr80211_demod_batch(
+            self.h, C.c_void_p(iq0.data_ptr()), C.c_void_p(iq1.data_ptr()) if iq1 is not None else None,
+            iq0.numel(), dp, n_frames, flags, C.c_void_p(info.data_ptr()), C.byref(llr_ptr), C.byref(nfl),
+            self._stream())
+        self._check(rc, "gr80211_demod_batch")
+        self.sync()
+        llr = np.zeros(max(int(nfl.value), 1), dtype=np.float32)
+        if nfl.value:
+            self._check(self.lib.gr80211_copy_d2h(self.h, C.c_void_p(llr.ctypes.data), llr_ptr,
+                                                  int(nfl.value) * 4, self._stream()), "copy_d2h")
+        info_h = info.cpu().numpy().view(FRAME_INFO_DTYPE)
+        return info_h, llr[: int(nfl.value)]
+
+    def decode_batch(self, llr, desc, n_frames, out_stride=4104, want_bits=False, bits_stride=4104):
+        """LLRs -> PDUs.  llr: float32 CUDA tensor; desc: DEC_DESC_DTYPE ndarray or device bytes."""
+        t = self.torch
+        assert llr.is_cuda and llr.dtype == t.float32 and llr.is_contiguous()
+        out = t.empty((n_frames, out_stride), dtype=t.uint8, device=self.dev)
+        out_len = t.empty(n_frames, dtype=t.int32, device=self.dev)
+        n_pdu = t.empty(n_frames, dtype=t.int32, device=self.dev)
+        bits = t.zeros((n_frames, bits_stride), dtype=t.uint8, device=self.dev) if want_bits else None
+        dp, flags, keep = self._desc_arg(desc)
+        rc = self.lib.gr80211_decode_batch(
+            self.h, C.c_void_p(llr.data_ptr()), llr.numel(), dp, n_frames, flags,
+            C.c_void_p(out.data_ptr()), out_stride, C.c_void_p(out_len.data_ptr()),
+            C.c_void_p(n_pdu.data_ptr()), C.c_void_p(bits.data_ptr()) if bits is not None else None,
+            bits_stride if bits is not None else 0, self._stream())
+        self._check(rc, "gr80211_decode_batch")
+        return dict(out=out, out_len=out_len, n_pdu=n_pdu, bits=bits, _keep=keep)
+
+    @staticmethod
+    def pdus_of(res, i):
+        """Host-side view of frame i's published PDUs from an rx_batch/decode_batch result."""
+        ln = int(res["out_len"][i].item())
+        blob = bytes(res["out"][i, :ln].cpu().numpy())
+        return split_pdus(blob)

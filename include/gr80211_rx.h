@@ -1,0 +1,163 @@
+/*
+ * C-ABI of the MI355X-native 802.11 OFDM RX hot path (signal -> demod/demod2 -> decode).
+ *
+ * Plain C: opaque context handle, plain pointers and sizes, integer return codes.  This is
+ * the boundary a GNU Radio out-of-tree block (or any FFI: ctypes, cgo, JNI) binds to.  Each
+ * entry point names the reference interface it stands in for; paths are relative to the
+ * reference tree.
+ *
+ * Conventions
+ *  - Pointers named d_* are DEVICE pointers (HBM of the context's GPU); h_* are host pointers.
+ *  - All work is enqueued on `stream` (a hipStream_t passed as void*, NULL = the context's own
+ *    stream).  Calls return after the work is enqueued and the small bookkeeping copy the
+ *    pipeline needs has completed; results in device buffers are ready after the stream is
+ *    synchronised (gr80211_sync).
+ *  - No exceptions, no global state: malformed frames are dropped in-band (status field), as
+ *    the reference blocks do; API misuse returns a negative code and sets gr80211_last_error.
+ *  - A context is not thread-safe; distinct contexts are independent.
+ */
+#ifndef GR80211_RX_H
+#define GR80211_RX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GR80211_OK 0
+#define GR80211_ERR_ARG (-1)
+#define GR80211_ERR_HIP (-2)
+#define GR80211_ERR_NOMEM (-3)
+
+/* frame formats: C8P_F_L / C8P_F_HT / C8P_F_VHT (lib/cloud80211phy.h:35-37) */
+#define GR80211_F_L 0
+#define GR80211_F_HT 1
+#define GR80211_F_VHT 2
+
+/* per-frame status */
+#define GR80211_ST_OK 0
+#define GR80211_ST_DROP_LSIG 1        /* signal: L-SIG check failed (lib/signal_impl.cc:156-160) */
+#define GR80211_ST_DROP_LEN_CHECK 2   /* demod: HT/VHT length sanity failed (lib/demod_impl.cc:159,186) */
+#define GR80211_ST_DROP_UNSUPPORTED 3 /* nSS>2, MU group id, NDP, VHT MCS>9 */
+#define GR80211_ST_DROP_DECODE_LIMIT 4/* decode: len>4095 or trellis>32782 (lib/decode_impl.cc:93) */
+
+#define GR80211_MAX_TRELLIS 32782 /* DECODE_T_MAX, lib/decode_impl.h:36 */
+#define GR80211_MAX_PSDU 4095     /* DECODE_B_MAX, lib/decode_impl.h:35 */
+
+typedef struct gr80211_ctx gr80211_ctx;
+
+/*
+ * One captured frame = what `sync` tells `signal` with its tagged trigger byte
+ * (lib/sync_impl.cc:122-136; read at lib/signal_impl.cc:83-92): where the frame is and the
+ * tags rad/snr/rssi.  sync_off is the sample index of the trigger byte (L-LTF start + 16) in
+ * the IQ arena(s); n_avail the number of samples of the capture available from there.
+ */
+typedef struct {
+    uint64_t sync_off;
+    uint32_t n_avail;
+    float rad;  /* CFO in rad/sample */
+    float snr;
+    float rssi;
+    uint32_t reserved[2];
+} gr80211_frame_desc; /* 32 bytes */
+
+/*
+ * Per-frame result record = the stream tags of the reference blocks:
+ * signal -> demod: cfo,snr,rssi,mcs,len,nsamp (lib/signal_impl.cc:135-152);
+ * demod -> decode: format,mcs,len,cr,ampdu,trellis,total,sssnr0/1 (lib/demod_impl.cc:224-253,
+ * lib/demod2_impl.cc:230-250); plus llr_off = offset of the frame's LLR run in the LLR arena.
+ */
+typedef struct {
+    int32_t status;
+    int32_t lsig_mcs, lsig_len, nsamp;
+    int32_t format, mcs, len, cr, ampdu, trellis, total;
+    int32_t nSym, nSS, nLTF, nCBPS, nDBPS, nBPSCS, mod;
+    float sssnr0, sssnr1;
+    float cfo_hz, snr, rssi;
+    int32_t slot;      /* internal: decoder lane assignment */
+    int64_t llr_off;   /* floats */
+    int32_t data_off;  /* first data symbol, samples after L-SIG */
+    int32_t nSymSamp;
+} gr80211_frame_info; /* 112 bytes */
+
+/*
+ * What `decode` reads from the tags on the first LLR of a packet (lib/decode_impl.cc:70-90).
+ */
+typedef struct {
+    int64_t llr_off; /* floats, into d_llr */
+    int32_t n_llr;   /* tag "total" */
+    int32_t format, len, cr, mcs, ampdu, trellis;
+    int32_t reserved;
+} gr80211_dec_desc; /* 40 bytes */
+
+#define GR80211_FLAG_DESC_ON_DEVICE 1u /* the descriptor array argument is a device pointer */
+
+/* Library/device set-up.  device = HIP device ordinal. */
+int gr80211_create(gr80211_ctx **out, int device);
+void gr80211_destroy(gr80211_ctx *ctx);
+const char *gr80211_last_error(gr80211_ctx *ctx);
+int gr80211_sync(gr80211_ctx *ctx, void *stream);
+
+/*
+ * Whole RX path for a batch of independent frames: the work of
+ *   ieee80211::signal/signal2::general_work (lib/signal_impl.cc:62-206, lib/signal2_impl.cc:63-212)
+ *   ieee80211::demod/demod2::general_work  (lib/demod_impl.cc:59-342, lib/demod2_impl.cc:58-349)
+ *   ieee80211::decode::general_work         (lib/decode_impl.cc:60-162)
+ * d_iq0/d_iq1: complex64 IQ arenas of antenna 1/2 (d_iq1 NULL = one-antenna `demod` path).
+ * d_out: n_frames slots of out_stride bytes; each receives the frame's PDU messages
+ *        concatenated in the layout `decode` publishes: [format][len lo][len hi][MPDU][mcs]
+ *        (lib/decode_impl.cc:359-361,414-419,512-516), only MPDUs whose FCS passes.
+ * d_out_len[i] = bytes written for frame i, d_n_pdu[i] = number of PDUs.
+ * d_info (nullable) receives the tag record of each frame.
+ */
+int gr80211_rx_batch(gr80211_ctx *ctx, const void *d_iq0, const void *d_iq1, uint64_t arena_len,
+                     const gr80211_frame_desc *desc, int n_frames, unsigned flags,
+                     uint8_t *d_out, int out_stride, int32_t *d_out_len, int32_t *d_n_pdu,
+                     gr80211_frame_info *d_info, void *stream);
+
+/*
+ * signal + demod only: IQ -> soft bits in the layout of the demod->decode stream, i.e. for each
+ * frame `total` floats in decoder order starting at info.llr_off of an internal LLR arena whose
+ * device address is returned in *d_llr (valid until the next call on this context).
+ * Stands for signal/signal2 + demod/demod2 ::general_work as above.
+ */
+int gr80211_demod_batch(gr80211_ctx *ctx, const void *d_iq0, const void *d_iq1, uint64_t arena_len,
+                        const gr80211_frame_desc *desc, int n_frames, unsigned flags,
+                        gr80211_frame_info *d_info, const float **d_llr, uint64_t *llr_floats,
+                        void *stream);
+
+/*
+ * decode only: soft bits -> PDUs.  Stands for ieee80211::decode::general_work + vstb_init /
+ * vstb_update / vstb_end / descramble / packetAssemble (lib/decode_impl.cc:60-520).
+ * d_bits (nullable): n_frames slots of bits_stride bytes receiving the descrambled bit array
+ * v_unCodedBits packed LSB-first (bit t of the frame at byte t/8, bit t%8).
+ */
+int gr80211_decode_batch(gr80211_ctx *ctx, const float *d_llr, uint64_t llr_floats,
+                         const gr80211_dec_desc *desc, int n_frames, unsigned flags,
+                         uint8_t *d_out, int out_stride, int32_t *d_out_len, int32_t *d_n_pdu,
+                         uint8_t *d_bits, int bits_stride, void *stream);
+
+/* Device memory helpers so that a C / FFI caller needs no HIP binding of its own. */
+void *gr80211_dev_alloc(gr80211_ctx *ctx, size_t bytes);
+void gr80211_dev_free(gr80211_ctx *ctx, void *p);
+int gr80211_copy_h2d(gr80211_ctx *ctx, void *d_dst, const void *h_src, size_t bytes, void *stream);
+int gr80211_copy_d2h(gr80211_ctx *ctx, void *h_dst, const void *d_src, size_t bytes, void *stream);
+
+/*
+ * Timing of the last batch call, measured with HIP events on the stream the kernels ran on.
+ * ms[0]=preamble, [1]=schedule, [2]=demod, [3]=viterbi forward, [4]=traceback+assemble, [5]=whole call.
+ * Only recorded when profiling is switched on (costs one stream synchronisation per call).
+ */
+int gr80211_set_profiling(gr80211_ctx *ctx, int on);
+int gr80211_last_timing(gr80211_ctx *ctx, float *ms, int n);
+
+/* Library self-description: build arch and table checksum (for load tests without a GPU). */
+const char *gr80211_version(void);
+uint32_t gr80211_table_checksum(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GR80211_RX_H */

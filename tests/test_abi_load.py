@@ -1,0 +1,40 @@
+"""The C-ABI library loads on a machine without a GPU and exports every symbol the header declares."""
+import ctypes
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    txt = open(os.path.join(ROOT, "include", "gr80211_rx.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(gr80211_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_header_symbols_exported(pkg):
+    names = declared_functions()
+    assert len(names) >= 14
+    lib = pkg.load_library()
+    for n in names:
+        assert hasattr(lib, n), n
+    assert sorted(pkg.rx.EXPORTS) == names
+
+
+def test_struct_sizes_match_header(pkg):
+    assert ctypes.sizeof(pkg.rx.FrameDesc) == 32
+    assert ctypes.sizeof(pkg.rx.FrameInfo) == 112
+    assert ctypes.sizeof(pkg.rx.DecDesc) == 40
+
+
+def test_version_and_tables(pkg):
+    lib = pkg.load_library()
+    assert b"gfx950" in lib.gr80211_version()
+    assert lib.gr80211_table_checksum() not in (0, 0xFFFFFFFF)
+
+
+def test_null_context_is_rejected(pkg):
+    lib = pkg.load_library()
+    assert lib.gr80211_sync(None, None) == -1
+    assert lib.gr80211_set_profiling(None, 1) == -1
+    assert lib.gr80211_last_error(None) == b"null context"

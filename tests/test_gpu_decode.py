@@ -1,0 +1,176 @@
+"""decode path on the GPU (gr80211_decode_batch) against the CPU oracle: bit-exact decoded bits,
+PDUs and FCS verdicts, for every code rate, ragged lengths, ties, erasures and edge cases."""
+import numpy as np
+import pytest
+
+from util import unpack_bits
+
+pytestmark = pytest.mark.gpu
+
+CR_KEEP = {0: [1, 1], 1: [1, 1, 1, 0], 2: [1, 1, 1, 0, 0, 1], 3: [1, 1, 1, 0, 0, 1, 1, 0, 0, 1]}
+
+
+def n_llr_for(trellis, cr):
+    pat = CR_KEEP[cr]
+    reps = -(-2 * trellis // len(pat))
+    return int(np.sum(np.tile(pat, reps)[: 2 * trellis]))
+
+
+def coded_frame(tx, rng, fmt, cr, nbytes, mcs=0, snr_scale=4.0, noise=1.0, integer=False):
+    """LLR stream of one frame whose PSDU is a valid MPDU (L/HT) or single-subframe A-MPDU (VHT)."""
+    mpdu = tx.make_mpdu(nbytes, rng)
+    if fmt == 2:
+        payload = tx.ampdu_vht([mpdu])
+        trellis = 16 + 8 * len(payload) + 6
+        pad = (-trellis) % {0: 1, 1: 2, 2: 3, 3: 5}[cr]
+        trellis += pad
+        bits = np.concatenate([np.zeros(16, np.uint8), np.unpackbits(np.frombuffer(payload, np.uint8), bitorder="little"),
+                               np.zeros(pad, np.uint8)])
+        scr = bits ^ tx.scramble_seq(len(bits), 93)
+        scr = np.concatenate([scr, np.zeros(6, np.uint8)])
+        length = len(payload)
+    else:
+        trellis = 16 + 8 * nbytes + 6
+        bits = np.concatenate([np.zeros(16, np.uint8), np.unpackbits(np.frombuffer(mpdu, np.uint8), bitorder="little"),
+                               np.zeros(6, np.uint8)])
+        scr = bits ^ tx.scramble_seq(len(bits), 93)
+        scr[-6:] = 0
+        length = nbytes
+    coded = tx.puncture(tx.bcc_encode(scr), cr)[: n_llr_for(trellis, cr)]
+    llr = (2.0 * coded - 1.0) * snr_scale + noise * rng.standard_normal(len(coded))
+    if integer:
+        llr = np.round(llr)
+    return dict(llr=llr.astype(np.float32), fmt=fmt, len=length, cr=cr, mcs=mcs, ampdu=1 if fmt == 2 else 0,
+                trellis=trellis, mpdu=mpdu)
+
+
+def run_and_compare(pkg, rxctx, oracle, frames, expect_all_ok=None):
+    import torch
+    rx = pkg.rx
+    n = len(frames)
+    desc = np.zeros(n, dtype=rx.DEC_DESC_DTYPE)
+    off = 0
+    parts = []
+    for i, f in enumerate(frames):
+        desc[i] = (off, len(f["llr"]), f["fmt"], f["len"], f["cr"], f["mcs"], f["ampdu"], f["trellis"], 0)
+        parts.append(f["llr"])
+        off += len(f["llr"]) + 3  # unaligned, non-contiguous runs
+        parts.append(np.full(3, np.nan, np.float32))
+    llr = torch.from_numpy(np.concatenate(parts)).cuda()
+    res = rxctx.decode_batch(llr, desc, n, want_bits=True)
+    rxctx.sync()
+    out_len = res["out_len"].cpu().numpy()
+    n_pdu = res["n_pdu"].cpu().numpy()
+    out = res["out"].cpu().numpy()
+    bits = res["bits"].cpu().numpy()
+    n_ok = 0
+    for i, f in enumerate(frames):
+        ref = oracle.decode(f["llr"], f["fmt"], f["len"], f["cr"], f["mcs"], f["ampdu"], f["trellis"], want_bits=True)
+        got_bits = unpack_bits(bits[i], f["trellis"])
+        assert np.array_equal(got_bits, ref["bits"]), "decoded bits differ, frame %d (cr %d T %d)" % (i, f["cr"], f["trellis"])
+        assert int(n_pdu[i]) == ref["n_pdu"], i
+        assert bytes(out[i, : out_len[i]]) == ref["blob"], i
+        n_ok += ref["n_pdu"]
+    if expect_all_ok:
+        assert n_ok == n
+    return n_ok
+
+
+def test_all_rates_mixed_lengths(pkg, rxctx, oracle):
+    tx = pkg.txgen
+    rng = np.random.default_rng(11)
+    frames = []
+    for k in range(150):
+        cr = k % 4
+        fmt = (0, 1, 2)[k % 3]
+        frames.append(coded_frame(tx, rng, fmt, cr, int(rng.integers(20, 420)), mcs=k % 8))
+    run_and_compare(pkg, rxctx, oracle, frames, expect_all_ok=True)
+
+
+def test_low_snr_and_ties_bit_exact(pkg, rxctx, oracle):
+    """Small-integer LLRs make equal path metrics common: survivor choice on ties must match
+    the reference rule (strict '>' scanning predecessors in ascending order)."""
+    tx = pkg.txgen
+    rng = np.random.default_rng(12)
+    frames = []
+    for k in range(96):
+        frames.append(coded_frame(tx, rng, (0, 2)[k & 1], k % 4, int(rng.integers(30, 200)), snr_scale=1.0,
+                                  noise=1.5, integer=True))
+    run_and_compare(pkg, rxctx, oracle, frames)
+
+
+def test_erasures_and_pure_noise(pkg, rxctx, oracle):
+    tx = pkg.txgen
+    rng = np.random.default_rng(13)
+    frames = []
+    for k in range(40):
+        f = coded_frame(tx, rng, 0, k % 4, int(rng.integers(40, 300)))
+        if k % 3 == 0:
+            f["llr"][rng.random(len(f["llr"])) < 0.2] = 0.0       # erasures
+        elif k % 3 == 1:
+            f["llr"] = rng.standard_normal(len(f["llr"])).astype(np.float32)  # garbage: FCS must fail on both
+        frames.append(f)
+    run_and_compare(pkg, rxctx, oracle, frames)
+
+
+def test_edge_lengths(pkg, rxctx, oracle):
+    tx = pkg.txgen
+    rng = np.random.default_rng(14)
+    frames = [coded_frame(tx, rng, 0, 0, 14), coded_frame(tx, rng, 0, 2, 15), coded_frame(tx, rng, 1, 3, 17),
+              coded_frame(tx, rng, 0, 1, 4095), coded_frame(tx, rng, 0, 0, 4095), coded_frame(tx, rng, 2, 2, 4084),
+              coded_frame(tx, rng, 1, 3, 2301)]
+    # HT A-MPDU flag: the reference publishes nothing
+    f = coded_frame(tx, rng, 1, 0, 100)
+    f["ampdu"] = 1
+    frames.append(f)
+    # over the decoder's limits: dropped without output (lib/decode_impl.cc:93)
+    g = coded_frame(tx, rng, 0, 0, 100)
+    g["len"] = 4096
+    frames.append(g)
+    run_and_compare(pkg, rxctx, oracle, frames)
+
+
+def test_single_and_empty_batch(pkg, rxctx, oracle):
+    import torch
+    tx = pkg.txgen
+    rng = np.random.default_rng(15)
+    run_and_compare(pkg, rxctx, oracle, [coded_frame(tx, rng, 2, 2, 333)], expect_all_ok=True)
+    llr = torch.zeros(16, dtype=torch.float32, device="cuda")
+    res = rxctx.decode_batch(llr, np.zeros(0, dtype=pkg.rx.DEC_DESC_DTYPE), 0)
+    assert res["out"].shape[0] == 0
+
+
+def test_bad_descriptor_rejected(pkg, rxctx):
+    import torch
+    llr = torch.zeros(100, dtype=torch.float32, device="cuda")
+    desc = np.zeros(1, dtype=pkg.rx.DEC_DESC_DTYPE)
+    desc[0] = (50, 100, 0, 20, 0, 0, 0, 182, 0)   # runs past the arena
+    with pytest.raises(RuntimeError):
+        rxctx.decode_batch(llr, desc, 1)
+
+
+def test_linearity_property_full_size(pkg, rxctx, oracle):
+    """Full-size VHT MCS8-like frames (12168 trellis steps, rate 3/4): decode(encode(x)) = x for many
+    frames at once, and a spot check of a few of them against the oracle."""
+    import torch
+    tx = pkg.txgen
+    rng = np.random.default_rng(16)
+    frames = [coded_frame(tx, rng, 2, 2, 1496, mcs=8, snr_scale=3.0) for _ in range(130)]
+    rx = pkg.rx
+    n = len(frames)
+    desc = np.zeros(n, dtype=rx.DEC_DESC_DTYPE)
+    off = 0
+    for i, f in enumerate(frames):
+        desc[i] = (off, len(f["llr"]), f["fmt"], f["len"], f["cr"], f["mcs"], f["ampdu"], f["trellis"], 0)
+        off += len(f["llr"])
+    llr = torch.from_numpy(np.concatenate([f["llr"] for f in frames])).cuda()
+    res = rxctx.decode_batch(llr, desc, n)
+    rxctx.sync()
+    for i, f in enumerate(frames):
+        got = rxctx.pdus_of(res, i)
+        assert len(got) == 1 and got[0]["mpdu"] == f["mpdu"] and got[0]["mcs"] == 8 and got[0]["format"] == 2
+    for i in (0, 64, 129):
+        f = frames[i]
+        ref = oracle.decode(f["llr"], f["fmt"], f["len"], f["cr"], f["mcs"], f["ampdu"], f["trellis"])
+        ln = int(res["out_len"][i].item())
+        assert bytes(res["out"][i, :ln].cpu().numpy()) == ref["blob"]

@@ -1,0 +1,214 @@
+"""Whole RX path on the GPU (gr80211_rx_batch / gr80211_demod_batch) against the CPU oracle and the
+golden fixtures: PSDU bytes and FCS verdicts bit-exact, tags equal, soft bits within 1e-4 relative."""
+import numpy as np
+import pytest
+
+from util import H22, LLR_ATOL, LLR_RTOL, awgn, build_arena, golden_frames, ref_fixture_mpdu, ref_fixtures
+
+pytestmark = pytest.mark.gpu
+
+TAGS = ("status", "lsig_mcs", "lsig_len", "nsamp", "format", "mcs", "len", "cr", "ampdu", "trellis", "total",
+        "nSym", "nSS")
+
+
+def oracle_tags(f):
+    return dict(status=f.status, lsig_mcs=f.lsig_mcs, lsig_len=f.lsig_len, nsamp=f.nsamp, format=f.m.format,
+                mcs=f.m.mcs, len=f.m.len, cr=f.m.cr, ampdu=f.m.ampdu, trellis=f.trellis, total=f.total,
+                nSym=f.m.nSym, nSS=f.m.nSS)
+
+
+def run_rx(pkg, rxctx, oracle, frames, rads=None, check_llr=True, two_ant=None):
+    """frames: list of ([antenna arrays], sync_idx).  Compares GPU against oracle frame by frame."""
+    import torch
+    iq0, iq1, sync, navail = build_arena(frames)
+    if two_ant is False:
+        iq1 = None
+    n = len(frames)
+    rads = np.zeros(n, np.float32) if rads is None else np.asarray(rads, np.float32)
+    desc = rxctx.make_desc(sync, navail, rad=rads)
+    d0 = torch.from_numpy(iq0).cuda()
+    d1 = torch.from_numpy(iq1).cuda() if iq1 is not None else None
+    res = rxctx.rx_batch(d0, d1, desc, n)
+    rxctx.sync()
+    info = res["info"].cpu().numpy().view(pkg.rx.FRAME_INFO_DTYPE)
+    out_len = res["out_len"].cpu().numpy()
+    out = res["out"].cpu().numpy()
+    n_pdu = res["n_pdu"].cpu().numpy()
+    if check_llr:
+        info2, llr = rxctx.demod_batch(d0, d1, desc, n)
+    results = []
+    for i in range(n):
+        ref = oracle.rx_frame(iq0, iq1, int(sync[i]), float(rads[i]))
+        # the oracle sees the rest of the arena too; restrict it like the descriptor does
+        ref = oracle.rx_frame(iq0[: int(sync[i]) + int(navail[i])], None if iq1 is None else iq1[: int(sync[i]) + int(navail[i])],
+                              int(sync[i]), float(rads[i]))
+        st = ref["status"]
+        assert int(info["status"][i]) == st, (i, int(info["status"][i]), st)
+        if st == 0:
+            want = oracle_tags(ref["frame"])
+            got = {k: int(info[k][i]) for k in TAGS}
+            assert got == want, (i, got, want)
+            if ref["frame"].m.format == 2:
+                assert abs(float(info["sssnr0"][i]) - ref["frame"].sssnr0) <= 1e-3 * max(1.0, abs(ref["frame"].sssnr0))
+        assert int(n_pdu[i]) == ref["n_pdu"], (i, int(n_pdu[i]), ref["n_pdu"])
+        assert bytes(out[i, : out_len[i]]) == ref["blob"], i
+        if check_llr and st == 0:
+            o = int(info2["llr_off"][i])
+            g = llr[o: o + ref["frame"].total]
+            r = ref["llr"]
+            err = np.abs(g - r)
+            tol = LLR_RTOL * np.abs(r) + LLR_ATOL
+            assert np.all(err <= tol), (i, float(err.max()), int(np.argmax(err - tol)))
+        results.append(ref)
+    return results
+
+
+def test_reference_fixtures(pkg, rxctx, oracle):
+    exp = ref_fixture_mpdu()
+    fx = ref_fixtures()
+    r = run_rx(pkg, rxctx, oracle, [(fx[0][1], fx[0][2])])
+    assert r[0]["pdus"][0]["mpdu"] == exp
+    r = run_rx(pkg, rxctx, oracle, [(fx[1][1], fx[1][2])])
+    assert r[0]["pdus"][0]["mpdu"] == exp
+
+
+def test_golden_frames_siso(pkg, rxctx, oracle):
+    gf = [f for f in golden_frames() if f["nss"] == 1]
+    frames = [([f["iq"][0]], f["sync_idx"]) for f in gf]
+    r = run_rx(pkg, rxctx, oracle, frames, rads=[f["rad"] for f in gf])
+    for f, ref in zip(gf, r):
+        assert [p["mpdu"] for p in ref["pdus"]] == [f["mpdu"]], f["name"]
+
+
+def test_golden_frames_2x2(pkg, rxctx, oracle):
+    gf = [f for f in golden_frames() if f["nss"] == 2]
+    frames = [([f["iq"][0], f["iq"][1]], f["sync_idx"]) for f in gf]
+    r = run_rx(pkg, rxctx, oracle, frames)
+    for f, ref in zip(gf, r):
+        assert [p["mpdu"] for p in ref["pdus"]] == [f["mpdu"]], f["name"]
+
+
+def make_noisy(tx, rng, fmt, mcs, nss, nbytes, snr_db, cfo_hz=0.0):
+    mpdu = tx.make_mpdu(nbytes, rng)
+    sig, m = tx.gen_frame(fmt, mcs, nss, mpdu)
+    sig = sig * 12.0 * np.sqrt(m.nss)
+    if cfo_hz:
+        sig = sig * np.exp(1j * 2 * np.pi * cfo_hz / 20e6 * np.arange(sig.shape[1]))
+    rx = H22 @ sig if m.nss == 2 else sig
+    rx = awgn(rx, snr_db, rng)
+    pad = np.zeros((rx.shape[0], 30))
+    rx = np.concatenate([pad, rx, pad], axis=1).astype(np.complex64)
+    return ([rx[a] for a in range(rx.shape[0])], 30 + 176), mpdu
+
+
+def test_every_mcs_noisy_siso(pkg, rxctx, oracle):
+    tx = pkg.txgen
+    rng = np.random.default_rng(21)
+    frames, mpdus = [], []
+    for fmt, nm in ((0, 8), (1, 8), (2, 9)):
+        for mcs in range(nm):
+            for rep in range(2):
+                fr, mp = make_noisy(tx, rng, fmt, mcs, 1, int(rng.integers(30, 500)), 33.0)
+                frames.append(fr)
+                mpdus.append(mp)
+    r = run_rx(pkg, rxctx, oracle, frames)
+    ok = sum(1 for ref, mp in zip(r, mpdus) if [p["mpdu"] for p in ref["pdus"]] == [mp])
+    assert ok == len(frames)
+
+
+def test_every_mcs_noisy_2x2(pkg, rxctx, oracle):
+    tx = pkg.txgen
+    rng = np.random.default_rng(22)
+    frames, mpdus = [], []
+    for fmt, mcss in ((1, range(8, 16)), (2, range(0, 9))):
+        for mcs in mcss:
+            fr, mp = make_noisy(tx, rng, fmt, mcs, 2, int(rng.integers(40, 600)), 36.0)
+            frames.append(fr)
+            mpdus.append(mp)
+    # single-stream frames seen by the two-antenna path use antenna 1 only
+    for fmt, mcs in ((0, 3), (1, 4), (2, 6)):
+        fr, mp = make_noisy(tx, rng, fmt, mcs, 1, 200, 33.0)
+        fr = ([fr[0][0], np.zeros_like(fr[0][0])], fr[1])
+        frames.append(fr)
+        mpdus.append(mp)
+    r = run_rx(pkg, rxctx, oracle, frames)
+    ok = sum(1 for ref, mp in zip(r, mpdus) if [p["mpdu"] for p in ref["pdus"]] == [mp])
+    assert ok == len(frames)
+
+
+def test_cfo_derotation(pkg, rxctx, oracle):
+    tx = pkg.txgen
+    rng = np.random.default_rng(23)
+    frames, rads, mpdus = [], [], []
+    for fmt, mcs, cfo in ((0, 2, 120e3), (1, 5, -90e3), (2, 7, 232e3), (2, 8, -40e3)):
+        fr, mp = make_noisy(tx, rng, fmt, mcs, 1, 300, 35.0, cfo_hz=cfo)
+        frames.append(fr)
+        rads.append(-2 * np.pi * cfo / 20e6)
+        mpdus.append(mp)
+    r = run_rx(pkg, rxctx, oracle, frames, rads=rads)
+    for ref, mp in zip(r, mpdus):
+        assert [p["mpdu"] for p in ref["pdus"]] == [mp]
+
+
+def test_low_snr_same_verdicts(pkg, rxctx, oracle):
+    """At marginal SNR some frames fail the FCS: the GPU must fail exactly the same ones."""
+    tx = pkg.txgen
+    rng = np.random.default_rng(24)
+    frames = []
+    for k in range(48):
+        fmt, mcs = ((0, 6), (1, 7), (2, 8))[k % 3]
+        fr, _ = make_noisy(tx, rng, fmt, mcs, 1, 250, 21.0 + (k % 4))
+        frames.append(fr)
+    r = run_rx(pkg, rxctx, oracle, frames, check_llr=False)
+    n_ok = sum(ref["n_pdu"] for ref in r)
+    assert 0 < n_ok < len(frames)
+
+
+def test_garbage_and_truncated_frames_dropped(pkg, rxctx, oracle):
+    tx = pkg.txgen
+    rng = np.random.default_rng(25)
+    noise = (0.1 * (rng.standard_normal(3000) + 1j * rng.standard_normal(3000))).astype(np.complex64)
+    fr, _ = make_noisy(tx, rng, 2, 4, 1, 400, 35.0)
+    cut = ([fr[0][0][:1200]], fr[1])          # data symbols missing: zeros are read, FCS fails
+    short = ([fr[0][0][:300]], fr[1])         # fewer than 224 samples after the trigger
+    good, mp = make_noisy(tx, rng, 1, 3, 1, 90, 35.0)
+    r = run_rx(pkg, rxctx, oracle, [([noise], 400), cut, short, good], check_llr=False)
+    assert r[3]["pdus"][0]["mpdu"] == mp
+    assert r[0]["n_pdu"] == 0 and r[1]["n_pdu"] == 0 and r[2]["status"] == 1
+
+
+def test_vht_multi_subframe_ampdu(pkg, rxctx, oracle):
+    tx = pkg.txgen
+    rng = np.random.default_rng(26)
+    ms = [tx.make_mpdu(96, rng) for _ in range(3)]
+    sig, m = tx.gen_frame(tx.F_VHT, 6, 1, None, n_mpdu_list=ms)
+    rx = np.concatenate([np.zeros(30), sig[0] * 12.0, np.zeros(30)]).astype(np.complex64)
+    r = run_rx(pkg, rxctx, oracle, [([rx], 206)])
+    assert [p["mpdu"] for p in r[0]["pdus"]] == ms
+
+
+def test_full_size_batch_roundtrip(pkg, rxctx):
+    """BASELINE frame shape (VHT MCS8, 1500-byte A-MPDU, 30 dB): a few hundred frames in one batch,
+    every PSDU must come back bit-exact (encode -> channel -> decode round trip)."""
+    import torch
+    tx = pkg.txgen
+    rng = np.random.default_rng(27)
+    uniq = []
+    for k in range(6):
+        mp = tx.make_mpdu(1496, rng)
+        sig, m = tx.gen_frame(tx.F_VHT, 8, 1, mp)
+        uniq.append((sig[0] * 12.0, mp))
+    n = 200
+    L = 3920
+    arena = np.zeros(n * L + 64, dtype=np.complex64)
+    for i in range(n):
+        arena[i * L:(i + 1) * L] = awgn(uniq[i % 6][0], 30.0, rng)
+    sync = (np.arange(n) * L + 176).astype(np.uint64)
+    navail = np.full(n, L - 176, dtype=np.uint32)
+    res = rxctx.rx_batch(torch.from_numpy(arena).cuda(), None, rxctx.make_desc(sync, navail), n)
+    rxctx.sync()
+    n_pdu = res["n_pdu"].cpu().numpy()
+    assert int(n_pdu.sum()) == n
+    for i in (0, 1, 63, 64, 127, 199):
+        got = rxctx.pdus_of(res, i)
+        assert got[0]["mpdu"] == uniq[i % 6][1]

@@ -1,0 +1,62 @@
+"""Shared helpers of the parity tests."""
+import glob
+import os
+
+import numpy as np
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+H22 = np.array([[1.0, 0.5j], [0.4, -1.0]], dtype=np.complex128)
+LLR_RTOL = 1e-4   # relative tolerance on soft bits stated by the north star
+LLR_ATOL = 1e-4   # absolute floor (LLR units: constellation spacing = 2) for values near zero
+
+
+def golden_frames():
+    out = []
+    for fn in sorted(glob.glob(os.path.join(GOLDEN, "frame_*.npz"))):
+        z = np.load(fn)
+        out.append(dict(name=os.path.basename(fn)[6:-4], iq=z["iq"], sync_idx=int(z["sync_idx"]),
+                        rad=float(z["rad"]), mpdu=z["mpdu"].tobytes(), fmt=int(z["fmt"]), mcs=int(z["mcs"]),
+                        nss=int(z["nss"])))
+    return out
+
+
+def ref_fixture_mpdu():
+    with open(os.path.join(GOLDEN, "ref_fixture_mpdu.hex")) as fh:
+        return bytes.fromhex(fh.read().strip())
+
+
+def ref_fixtures():
+    """The reference's own IQ files: (name, [antenna arrays], sync_idx)."""
+    s = np.fromfile(os.path.join(GOLDEN, "sig80211GenMultipleSiso_1x1_0.bin"), dtype=np.complex64)
+    a = np.fromfile(os.path.join(GOLDEN, "sig80211GenMultipleMimo_2x2_0.bin"), dtype=np.complex64)
+    b = np.fromfile(os.path.join(GOLDEN, "sig80211GenMultipleMimo_2x2_1.bin"), dtype=np.complex64)
+    return [("ref_siso_l_mcs0", [s], 1200 + 176), ("ref_mimo_ht_mcs8", [a, b], 1200 + 176)]
+
+
+def build_arena(frames, gap=64):
+    """Lay frames (each: list of per-antenna complex arrays + sync index) into one arena per antenna.
+    Returns iq0, iq1 (or None), sync_off[], n_avail[]."""
+    nant = max(len(f[0]) for f in frames)
+    total = sum(len(f[0][0]) + gap for f in frames) + gap
+    iq = np.zeros((nant, total), dtype=np.complex64)
+    sync, navail = [], []
+    pos = gap
+    for ants, sidx in frames:
+        n = len(ants[0])
+        for a in range(nant):
+            if a < len(ants):
+                iq[a, pos:pos + n] = ants[a]
+        sync.append(pos + sidx)
+        navail.append(n - sidx)
+        pos += n + gap
+    return iq[0], (iq[1] if nant > 1 else None), np.array(sync, dtype=np.uint64), np.array(navail, dtype=np.uint32)
+
+
+def awgn(sig, snr_db, rng):
+    p = np.mean(np.abs(sig) ** 2)
+    sigma = np.sqrt(p / (10 ** (snr_db / 10.0)) / 2.0)
+    return sig + sigma * (rng.standard_normal(sig.shape) + 1j * rng.standard_normal(sig.shape))
+
+
+def unpack_bits(bytes_row, nbits):
+    return np.unpackbits(np.asarray(bytes_row, dtype=np.uint8), bitorder="little")[:nbits]
