@@ -955,11 +955,52 @@ __device__ __forceinline__ void acs_one(const float (&m)[64], float (&o)[64], fl
     dw = (dw << 1) | (g ? 1u : 0u);
 }
 
+// Four add-compare-select updates in one hand-scheduled block: 4 compares into scalar masks, 4
+// selects, 4 add-with-carry that shift each survivor bit into the decision word.  Keeping the
+// compares three instructions ahead of their first use covers the VALU-writes-SGPR wait states,
+// so no s_nop is needed (the compiler pads its own cmp/cndmask pairs with s_nop on gfx950).
+template <int KIND, int N>
+__device__ __forceinline__ void acs_quad(const float (&m)[64], float (&o)[64], float t0, float t1, float t01, uint32_t &dw)
+{
+    float a0[4], a1[4];
+#define GR_ACS_IN(K)                                                              \
+    {                                                                             \
+        constexpr int n = N + K, j = n & 31, b = n >> 5, p0 = 2 * j, p1 = 2 * j + 1; \
+        a0[K] = add_tab<KIND, sv_out(p0, b)>(m[p0], t0, t1, t01);                 \
+        a1[K] = add_tab<KIND, sv_out(p1, b)>(m[p1], t0, t1, t01);                 \
+    }
+    GR_ACS_IN(0) GR_ACS_IN(1) GR_ACS_IN(2) GR_ACS_IN(3)
+#undef GR_ACS_IN
+    float r0, r1, r2, r3;
+    unsigned long long c0, c1, c2, c3, cy;
+    asm("v_cmp_gt_f32_e64 %[c0], %[b0], %[a0]\n\t"
+        "v_cmp_gt_f32_e64 %[c1], %[b1], %[a1]\n\t"
+        "v_cmp_gt_f32_e64 %[c2], %[b2], %[a2]\n\t"
+        "v_cmp_gt_f32_e64 %[c3], %[b3], %[a3]\n\t"
+        "v_cndmask_b32_e64 %[r0], %[a0], %[b0], %[c0]\n\t"
+        "v_cndmask_b32_e64 %[r1], %[a1], %[b1], %[c1]\n\t"
+        "v_cndmask_b32_e64 %[r2], %[a2], %[b2], %[c2]\n\t"
+        "v_cndmask_b32_e64 %[r3], %[a3], %[b3], %[c3]\n\t"
+        "v_addc_co_u32_e64 %[dw], %[cy], %[dw], %[dw], %[c0]\n\t"
+        "v_addc_co_u32_e64 %[dw], %[cy], %[dw], %[dw], %[c1]\n\t"
+        "v_addc_co_u32_e64 %[dw], %[cy], %[dw], %[dw], %[c2]\n\t"
+        "v_addc_co_u32_e64 %[dw], %[cy], %[dw], %[dw], %[c3]"
+        : [r0] "=&v"(r0), [r1] "=&v"(r1), [r2] "=&v"(r2), [r3] "=&v"(r3), [dw] "+v"(dw), [c0] "=&s"(c0),
+          [c1] "=&s"(c1), [c2] "=&s"(c2), [c3] "=&s"(c3), [cy] "=&s"(cy)
+        : [a0] "v"(a0[0]), [b0] "v"(a1[0]), [a1] "v"(a0[1]), [b1] "v"(a1[1]), [a2] "v"(a0[2]), [b2] "v"(a1[2]),
+          [a3] "v"(a0[3]), [b3] "v"(a1[3]));
+    o[N] = r0; o[N + 1] = r1; o[N + 2] = r2; o[N + 3] = r3;
+}
+
 template <int KIND, int BASE, int... N>
 __device__ __forceinline__ void acs_range(const float (&m)[64], float (&o)[64], float t0, float t1, float t01,
                                           uint32_t &dw, std::integer_sequence<int, N...>)
 {
+#ifdef GR80211_PLAIN_ACS
     (acs_one<KIND, BASE + N>(m, o, t0, t1, t01, dw), ...);
+#else
+    (acs_quad<KIND, BASE + 4 * N>(m, o, t0, t1, t01, dw), ...);
+#endif
 }
 
 // One trellis step for 64 frames.  Survivor bit of state n lands in bit 31-(n&31) of word n>>5.
@@ -968,8 +1009,13 @@ __device__ __forceinline__ void acs_step(const float (&m)[64], float (&o)[64], f
 {
     const float t01 = t1 + t0;
     uint32_t d0 = 0, d1 = 0;
+#ifdef GR80211_PLAIN_ACS
     acs_range<KIND, 0>(m, o, t0, t1, t01, d0, std::make_integer_sequence<int, 32>{});
     acs_range<KIND, 32>(m, o, t0, t1, t01, d1, std::make_integer_sequence<int, 32>{});
+#else
+    acs_range<KIND, 0>(m, o, t0, t1, t01, d0, std::make_integer_sequence<int, 8>{});
+    acs_range<KIND, 32>(m, o, t0, t1, t01, d1, std::make_integer_sequence<int, 8>{});
+#endif
     dec[0] = d0;
     dec[64] = d1;
 }
