@@ -268,6 +268,7 @@ int gr80211_rx_batch(gr80211_ctx *c, const void *d_iq0, const void *d_iq1, uint6
                      int32_t *d_out_len, int32_t *d_n_pdu, gr80211_frame_info *d_info, void *stream)
 {
     if (!c) return GR80211_ERR_ARG;
+    if (n == 0) return GR80211_OK;
     if (!d_iq0 || !desc || n < 0 || !d_out || !d_out_len || !d_n_pdu || out_stride < 8)
         return fail(c, GR80211_ERR_ARG, "gr80211_rx_batch: bad argument");
     if (n > (1 << 20)) return fail(c, GR80211_ERR_ARG, "gr80211_rx_batch: at most 1048576 frames per call");
@@ -313,6 +314,7 @@ int gr80211_decode_batch(gr80211_ctx *c, const float *d_llr, uint64_t llr_floats
                          uint8_t *d_bits, int bits_stride, void *stream)
 {
     if (!c) return GR80211_ERR_ARG;
+    if (n == 0) return GR80211_OK;
     if (!d_llr || !desc || n < 0 || !d_out || !d_out_len || !d_n_pdu || out_stride < 8)
         return fail(c, GR80211_ERR_ARG, "gr80211_decode_batch: bad argument");
     if (d_bits && (bits_stride < 4 || (bits_stride & 3)))

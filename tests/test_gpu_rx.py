@@ -49,7 +49,10 @@ def run_rx(pkg, rxctx, oracle, frames, rads=None, check_llr=True, two_ant=None):
             got = {k: int(info[k][i]) for k in TAGS}
             assert got == want, (i, got, want)
             if ref["frame"].m.format == 2:
-                assert abs(float(info["sssnr0"][i]) - ref["frame"].sssnr0) <= 1e-3 * max(1.0, abs(ref["frame"].sssnr0))
+                # per-stream SNR from the re-encoded VHT-SIG-B.  On noise-free input the "noise" is float
+                # rounding (> 100 dB), where only the order of magnitude is meaningful.
+                a, b = float(info["sssnr0"][i]), ref["frame"].sssnr0
+                assert abs(a - b) <= 1e-3 * max(1.0, abs(b)) if b < 80.0 else a > 80.0, (i, a, b)
         assert int(n_pdu[i]) == ref["n_pdu"], (i, int(n_pdu[i]), ref["n_pdu"])
         assert bytes(out[i, : out_len[i]]) == ref["blob"], i
         if check_llr and st == 0:
