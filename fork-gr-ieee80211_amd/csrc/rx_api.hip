@@ -23,7 +23,7 @@ struct gr80211_ctx {
     hipStream_t stream = nullptr;
     std::string err;
     // workspaces (grown on demand, never shrunk)
-    Buf desc, ddesc, info, chan1, chan2, llr, slot_frame, groups, dec, bitsw, totals_d;
+    Buf desc, ddesc, info, chan1, chan2, llr, slot_frame, groups, dec, bitsw, totals_d, sched_ws, blk_llr;
     SchedTotals *totals_h = nullptr;  // pinned
     bool profiling = false;
     hipEvent_t ev[7] = {};
@@ -122,10 +122,13 @@ int run_decode_stages(gr80211_ctx *c, hipStream_t s, int n, bool from_iq, const 
     if ((rc = ensure(c, c->slot_frame, (size_t)slot_cap * sizeof(int32_t)))) return rc;
     if ((rc = ensure(c, c->groups, (size_t)group_cap * sizeof(GroupInfo)))) return rc;
     if ((rc = ensure(c, c->totals_d, sizeof(SchedTotals)))) return rc;
+    if ((rc = ensure(c, c->sched_ws, (size_t)SCHED_WS_WORDS * sizeof(uint32_t)))) return rc;
+    if ((rc = ensure(c, c->blk_llr, (size_t)(n / 256 + 2) * sizeof(unsigned long long)))) return rc;
     gr80211_frame_info *info = (gr80211_frame_info *)c->info.p;
 
     launch_schedule(info, n, from_iq ? 1 : 0, (int32_t *)c->slot_frame.p, slot_cap, (GroupInfo *)c->groups.p,
-                    group_cap, (SchedTotals *)c->totals_d.p, s);
+                    group_cap, (SchedTotals *)c->totals_d.p, (uint32_t *)c->sched_ws.p,
+                    (unsigned long long *)c->blk_llr.p, s);
     mark(c, 2, s);
     HIP_TRY(c, hipMemcpyAsync(c->totals_h, c->totals_d.p, sizeof(SchedTotals), hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
@@ -245,7 +248,7 @@ void gr80211_destroy(gr80211_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (Buf *b : {&c->desc, &c->ddesc, &c->info, &c->chan1, &c->chan2, &c->llr, &c->slot_frame, &c->groups, &c->dec,
-                   &c->bitsw, &c->totals_d})
+                   &c->bitsw, &c->totals_d, &c->sched_ws, &c->blk_llr})
         release(*b);
     if (c->totals_h) (void)hipHostFree(c->totals_h);
     for (auto &e : c->ev)

@@ -25,6 +25,7 @@ struct SchedTotals {
 };
 
 constexpr int SCHED_NB = 513;  // trellis-length bins of 64 steps
+constexpr int SCHED_WS_WORDS = 4 * SCHED_NB + 8;  // scheduler scratch: bin counters, rate starts, valid count
 
 // steps per LLR tile for each code rate (whole puncture periods)
 __host__ __device__ constexpr int chunk_steps(int cr) { return cr == CR_12 ? 32 : cr == CR_23 ? 40 : cr == CR_34 ? 48 : 50; }
@@ -35,7 +36,8 @@ void launch_preamble(const void *iq0, const void *iq1, uint64_t arena_len, const
                      int n, gr80211_frame_info *info, void *chan1, void *chan2, hipStream_t s);
 void launch_desc_to_info(const gr80211_dec_desc *desc, int n, gr80211_frame_info *info, hipStream_t s);
 void launch_schedule(gr80211_frame_info *info, int n, int assign_llr, int32_t *slot_frame, int slot_cap,
-                     GroupInfo *groups, int group_cap, SchedTotals *totals, hipStream_t s);
+                     GroupInfo *groups, int group_cap, SchedTotals *totals, uint32_t *ws, unsigned long long *blk_llr,
+                     hipStream_t s);
 void launch_demod(const void *iq0, const void *iq1, const gr80211_frame_desc *desc, int n,
                   const gr80211_frame_info *info, const void *chan1, const void *chan2, float *llr,
                   hipStream_t s);

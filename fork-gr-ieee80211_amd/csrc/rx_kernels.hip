@@ -3,7 +3,7 @@
 //   k_preamble   one wavefront per frame: CFO-derotated L-LTF/L-SIG FFTs, LS channel estimate,
 //                L-SIG / HT-SIG / VHT-SIG-A / VHT-SIG-B soft decoding (lane = trellis state),
 //                HT/VHT channel estimate incl. the 2x2 Gram inverse.
-//   k_schedule   buckets frames by code rate and trellis length into groups of 64 (decoder lanes).
+//   k_sched_*    bucket frames by code rate and trellis length into groups of 64 (decoder lanes).
 //   k_demod      one wavefront per OFDM symbol: FFT-64 by lane shuffles, one-tap or 2x2 ZF
 //                equalisation, pilot phase tracking, QAM soft demap, deinterleave / stream deparse
 //                folded into the store address.
@@ -635,104 +635,192 @@ __global__ void k_desc_to_info(const gr80211_dec_desc *__restrict__ desc, int n,
     fi.status = GR80211_ST_OK;
     fi.format = d.format; fi.len = d.len; fi.cr = d.cr; fi.mcs = d.mcs; fi.ampdu = d.ampdu;
     fi.trellis = d.trellis; fi.total = d.n_llr; fi.llr_off = d.llr_off; fi.slot = -1;
-    if (d.cr < 0 || d.cr > 3 || d.n_llr < 0 || d.llr_off < 0) fi.status = GR80211_ST_DROP_UNSUPPORTED;
+    if (d.cr < 0 || d.cr > 3 || d.n_llr < 0 || d.llr_off < 0) {
+        fi.status = GR80211_ST_DROP_UNSUPPORTED;
+    } else if (d.trellis > 0 && d.trellis <= GR80211_MAX_TRELLIS) {
+        // soft bits the trellis consumes; with fewer the reference block would wait for more input
+        // and never finish the packet (lib/decode_impl.cc:210)
+        const int P = d.cr == CR_12 ? 1 : d.cr == CR_23 ? 2 : d.cr == CR_34 ? 3 : 5;
+        const int q = d.trellis / P, rem = d.trellis % P;
+        const int need = q * (P + 1) + (rem ? rem + 1 : 0);
+        if (d.n_llr < need) fi.status = GR80211_ST_DROP_DECODE_LIMIT;
+    }
     info[i] = fi;
 }
 
 // =========================================================================================
-// k_schedule (single workgroup)
+// scheduler: decode admission, counting sort by (code rate, trellis/64) into groups of 64 lanes,
+// LLR arena offsets.  Four small kernels: histogram -> scan -> assign -> group offsets.
 // =========================================================================================
 __device__ __forceinline__ uint32_t round64(uint32_t v) { return (v + 63u) & ~63u; }
 
-__global__ __launch_bounds__(1024) void k_schedule(gr80211_frame_info *__restrict__ info, int n, int assign_llr,
-                                                   int32_t *__restrict__ slot_frame, int slot_cap,
-                                                   GroupInfo *__restrict__ groups, int group_cap,
-                                                   SchedTotals *__restrict__ totals)
+constexpr int SCHED_BINS = 4 * SCHED_NB;
+constexpr int SCHED_BLOCK = 256;
+
+// ws layout (uint32): [0, SCHED_BINS) histogram -> bin cursors; then crstart[5]; then n_valid.
+__device__ __forceinline__ bool llr_eligible(int st) { return st == GR80211_ST_OK || st == GR80211_ST_DROP_DECODE_LIMIT; }
+
+__global__ __launch_bounds__(SCHED_BLOCK) void k_sched_hist(gr80211_frame_info *__restrict__ info, int n,
+                                                            uint32_t *__restrict__ ws,
+                                                            unsigned long long *__restrict__ blk_llr)
 {
-    __shared__ uint32_t hist[4 * SCHED_NB];
-    __shared__ uint32_t crstart[5];
-    __shared__ unsigned long long part[1024];
-    __shared__ unsigned long long part2[1024];
-    __shared__ int s_nvalid;
-    const int tid = threadIdx.x;
-    for (int k = tid; k < 4 * SCHED_NB; k += 1024) hist[k] = 0;
-    if (tid == 0) s_nvalid = 0;
+    __shared__ unsigned long long red[SCHED_BLOCK];
+    __shared__ uint32_t lh[SCHED_BINS];  // block-private histogram: batches of equal frames hit one bin
+    for (int k = threadIdx.x; k < SCHED_BINS; k += SCHED_BLOCK) lh[k] = 0;
     __syncthreads();
-
-    const int per = (n + 1023) / 1024;
-    const int i0 = tid * per < n ? tid * per : n;
-    const int i1 = i0 + per < n ? i0 + per : n;
-
-    // pass 1: decode admission (lib/decode_impl.cc:93), histogram, LLR space per thread
-    unsigned long long sum = 0;
-    int nv = 0;
-    for (int i = i0; i < i1; i++) {
+    const int i = blockIdx.x * SCHED_BLOCK + threadIdx.x;
+    unsigned long long mine = 0;
+    if (i < n) {
         int st = info[i].status;
         const int tr = info[i].trellis, len = info[i].len, cr = info[i].cr;
+        // decode admission (lib/decode_impl.cc:93)
         if (st == GR80211_ST_OK && (len > GR80211_MAX_PSDU || tr > GR80211_MAX_TRELLIS || tr <= 0 || cr < 0 || cr > 3)) {
             st = GR80211_ST_DROP_DECODE_LIMIT;
             info[i].status = st;
         }
-        if (st == GR80211_ST_OK) {
-            atomicAdd(&hist[cr * SCHED_NB + tr / 64], 1u);
-            nv++;
-        }
-        if (st == GR80211_ST_OK || st == GR80211_ST_DROP_DECODE_LIMIT) sum += (unsigned long long)info[i].total;
+        if (st == GR80211_ST_OK) atomicAdd(&lh[cr * SCHED_NB + tr / 64], 1u);
+        if (llr_eligible(st)) mine = (unsigned long long)info[i].total;
     }
+    red[threadIdx.x] = mine;
+    __syncthreads();
+    for (int k = threadIdx.x; k < SCHED_BINS; k += SCHED_BLOCK)
+        if (lh[k]) atomicAdd(&ws[k], lh[k]);
+    for (int o = SCHED_BLOCK / 2; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) blk_llr[blockIdx.x] = red[0];
+}
+
+// Single workgroup: exclusive scans of the bin histogram (code-rate starts aligned to 64 lanes) and of
+// the per-block LLR sums.
+__global__ __launch_bounds__(1024) void k_sched_scan(uint32_t *__restrict__ ws, unsigned long long *__restrict__ blk_llr,
+                                                     int nblk, int assign_llr, int slot_cap, int group_cap,
+                                                     int32_t *__restrict__ slot_frame, GroupInfo *__restrict__ groups,
+                                                     SchedTotals *__restrict__ totals)
+{
+    __shared__ unsigned long long part[1024];
+    __shared__ uint32_t binpart[1024];
+    __shared__ uint32_t crs[5];
+    const int tid = threadIdx.x;
+    // --- LLR block sums
+    const int per = (nblk + 1023) / 1024;
+    const int b0 = tid * per < nblk ? tid * per : nblk;
+    const int b1 = b0 + per < nblk ? b0 + per : nblk;
+    unsigned long long sum = 0;
+    for (int b = b0; b < b1; b++) sum += blk_llr[b];
     part[tid] = sum;
-    if (nv) atomicAdd(&s_nvalid, nv);
+    // --- bins: thread t owns bins [3t, 3t+3) of the 2052 (684 threads)
+    uint32_t bsum = 0;
+    for (int k = 0; k < 3; k++) {
+        const int b = tid * 3 + k;
+        if (b < SCHED_BINS) bsum += ws[b];
+    }
+    binpart[tid] = bsum;
     __syncthreads();
     if (tid == 0) {
         unsigned long long run = 0;
         for (int k = 0; k < 1024; k++) { const unsigned long long v = part[k]; part[k] = run; run += v; }
         totals->llr_floats = assign_llr ? run : 0;
-        uint32_t p = 0;
+        // SCHED_NB = 513 bins per rate = 171 threads per rate
+        uint32_t p = 0, cnt = 0;
         for (int cr = 0; cr < 4; cr++) {
             p = round64(p);
-            crstart[cr] = p;
-            for (int b = 0; b < SCHED_NB; b++) { const uint32_t c = hist[cr * SCHED_NB + b]; hist[cr * SCHED_NB + b] = p; p += c; }
+            crs[cr] = p;
+            for (int k = cr * 171; k < (cr + 1) * 171; k++) { const uint32_t v = binpart[k]; binpart[k] = p; p += v; cnt += v; }
         }
-        crstart[4] = round64(p);
+        crs[4] = round64(p);
+        totals->n_valid = (int)cnt;
     }
     __syncthreads();
-    const int n_slots = (int)crstart[4];
-    const int n_groups = n_slots / 64;
-    if (n_slots > slot_cap || n_groups > group_cap) {  // host sized these from n; cannot happen
-        if (tid == 0) { totals->n_groups = -1; totals->n_valid = 0; totals->dec_words = 0; totals->bits_words = 0; }
-        return;
-    }
-    if (assign_llr) {
+    {
         unsigned long long run = part[tid];
-        for (int i = i0; i < i1; i++) {
-            const int st = info[i].status;
-            if (st == GR80211_ST_OK || st == GR80211_ST_DROP_DECODE_LIMIT) {
-                info[i].llr_off = (int64_t)run;
-                run += (unsigned long long)info[i].total;
-            }
+        for (int b = b0; b < b1; b++) { const unsigned long long v = blk_llr[b]; blk_llr[b] = run; run += v; }
+        uint32_t p = binpart[tid];
+        for (int k = 0; k < 3; k++) {
+            const int b = tid * 3 + k;
+            if (b < SCHED_BINS) { const uint32_t v = ws[b]; ws[b] = p; p += v; }
         }
+        if (tid < 5) ws[SCHED_BINS + tid] = crs[tid];
     }
-    for (int s = tid; s < n_slots; s += 1024) slot_frame[s] = -1;
+    const int n_slots = (int)crs[4];
+    const int n_groups = n_slots / 64;
+    if (tid == 0) {
+        totals->n_groups = (n_slots > slot_cap || n_groups > group_cap) ? -1 : n_groups;
+    }
+    if (n_slots > slot_cap || n_groups > group_cap) return;
+    for (int sl = tid; sl < n_slots; sl += 1024) slot_frame[sl] = -1;
     for (int g = tid; g < n_groups; g += 1024) {
         const uint32_t s0 = (uint32_t)g * 64u;
         GroupInfo gi;
-        gi.cr = s0 >= crstart[3] ? 3 : s0 >= crstart[2] ? 2 : s0 >= crstart[1] ? 1 : 0;
+        gi.cr = s0 >= crs[3] ? 3 : s0 >= crs[2] ? 2 : s0 >= crs[1] ? 1 : 0;
         gi.steps = 0; gi.nchunks = 0; gi.words = 0; gi.dec_off = 0; gi.bits_off = 0;
         groups[g] = gi;
     }
+}
+
+__global__ __launch_bounds__(SCHED_BLOCK) void k_sched_assign(gr80211_frame_info *__restrict__ info, int n, int assign_llr,
+                                                              uint32_t *__restrict__ ws,
+                                                              const unsigned long long *__restrict__ blk_llr,
+                                                              int32_t *__restrict__ slot_frame,
+                                                              GroupInfo *__restrict__ groups,
+                                                              const SchedTotals *__restrict__ totals)
+{
+    __shared__ unsigned long long sc[SCHED_BLOCK];
+    __shared__ uint32_t lh[SCHED_BINS];
+    __shared__ uint32_t lbase[SCHED_BINS];
+    if (totals->n_groups < 0) return;
+    const int i = blockIdx.x * SCHED_BLOCK + threadIdx.x;
+    int st = GR80211_ST_DROP_LSIG;
+    unsigned long long mine = 0;
+    if (i < n) {
+        st = info[i].status;
+        if (llr_eligible(st)) mine = (unsigned long long)info[i].total;
+    }
+    // block-level exclusive scan keeps the LLR runs in frame order
+    sc[threadIdx.x] = mine;
     __syncthreads();
-    // pass 2: slots
-    for (int i = i0; i < i1; i++) {
-        if (info[i].status == GR80211_ST_OK) {
-            const int tr = info[i].trellis;
-            const uint32_t slot = atomicAdd(&hist[info[i].cr * SCHED_NB + tr / 64], 1u);
-            info[i].slot = (int32_t)slot;
-            slot_frame[slot] = i;
-            atomicMax(&groups[slot / 64].steps, tr);
-        } else {
-            info[i].slot = -1;
-        }
+    for (int o = 1; o < SCHED_BLOCK; o <<= 1) {
+        unsigned long long v = 0;
+        if ((int)threadIdx.x >= o) v = sc[threadIdx.x - o];
+        __syncthreads();
+        sc[threadIdx.x] += v;
+        __syncthreads();
+    }
+    // slots: rank inside the block through a block-private histogram, one global atomic per used bin
+    for (int k = threadIdx.x; k < SCHED_BINS; k += SCHED_BLOCK) lh[k] = 0;
+    __syncthreads();
+    int bin = -1;
+    uint32_t rank = 0;
+    if (i < n && st == GR80211_ST_OK) {
+        bin = info[i].cr * SCHED_NB + info[i].trellis / 64;
+        rank = atomicAdd(&lh[bin], 1u);
     }
     __syncthreads();
+    for (int k = threadIdx.x; k < SCHED_BINS; k += SCHED_BLOCK) {
+        const uint32_t c = lh[k];
+        if (c) lbase[k] = atomicAdd(&ws[k], c);
+    }
+    __syncthreads();
+    if (i >= n) return;
+    if (assign_llr && llr_eligible(st)) info[i].llr_off = (int64_t)(blk_llr[blockIdx.x] + sc[threadIdx.x] - mine);
+    if (bin >= 0) {
+        const uint32_t slot = lbase[bin] + rank;
+        info[i].slot = (int32_t)slot;
+        slot_frame[slot] = i;
+        atomicMax(&groups[slot / 64].steps, info[i].trellis);
+    } else {
+        info[i].slot = -1;
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_sched_groups(GroupInfo *__restrict__ groups, SchedTotals *__restrict__ totals)
+{
+    __shared__ unsigned long long part[1024];
+    __shared__ unsigned long long part2[1024];
+    const int n_groups = totals->n_groups;
+    const int tid = threadIdx.x;
+    if (n_groups < 0) return;
     const int gper = (n_groups + 1023) / 1024;
     const int g0 = tid * gper < n_groups ? tid * gper : n_groups;
     const int g1 = g0 + gper < n_groups ? g0 + gper : n_groups;
@@ -759,8 +847,6 @@ __global__ __launch_bounds__(1024) void k_schedule(gr80211_frame_info *__restric
         }
         totals->dec_words = r1;
         totals->bits_words = r2;
-        totals->n_groups = n_groups;
-        totals->n_valid = s_nvalid;
     }
     __syncthreads();
     unsigned long long r1 = part[tid], r2 = part2[tid];
@@ -770,6 +856,12 @@ __global__ __launch_bounds__(1024) void k_schedule(gr80211_frame_info *__restric
         r1 += (unsigned long long)groups[g].steps * 128ull;
         r2 += (unsigned long long)groups[g].words * 64ull;
     }
+}
+
+__global__ void k_zero_u32(uint32_t *p, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0;
 }
 
 // =========================================================================================
@@ -950,9 +1042,20 @@ __device__ __forceinline__ void acs_one(const float (&m)[64], float (&o)[64], fl
     constexpr int o0 = sv_out(p0, b), o1 = sv_out(p1, b);
     const float a0 = add_tab<KIND, o0>(m[p0], t0, t1, t01);
     const float a1 = add_tab<KIND, o1>(m[p1], t0, t1, t01);
+#if defined(GR80211_PLAIN_ACS)
     const bool g = a1 > a0;  // strict: ties keep the even predecessor (lib/decode_impl.cc:248-258)
     o[N] = g ? a1 : a0;
     dw = (dw << 1) | (g ? 1u : 0u);
+#else
+    // Register-only form of "a1 > a0 ? a1 : a0" plus survivor bit, three VALU instructions and no
+    // scalar mask: the metric is max(a0, a1); the decision is the sign of a0 - a1, which is set
+    // exactly when a1 > a0 (two distinct floats never subtract to zero with subnormals enabled, and
+    // a tie gives +0, i.e. the even predecessor as the reference's strict '>' does,
+    // lib/decode_impl.cc:248-258); v_alignbit shifts it into the decision word.
+    const float diff = a0 - a1;
+    o[N] = fmaxf(a0, a1);
+    dw = __builtin_amdgcn_alignbit(dw, __float_as_uint(diff), 31);
+#endif
 }
 
 // Four add-compare-select updates in one hand-scheduled block: 4 compares into scalar masks, 4
@@ -992,32 +1095,84 @@ __device__ __forceinline__ void acs_quad(const float (&m)[64], float (&o)[64], f
     o[N] = r0; o[N + 1] = r1; o[N + 2] = r2; o[N + 3] = r3;
 }
 
+// Four state updates written phase by phase (adds, subtracts, maxima, decision shifts) so that no
+// instruction sits next to the one it depends on: on gfx950 a dependent VALU pair costs ~9.5 cycles
+// against ~4.3 for independent issue from one wave.  Each of the four states feeds its own decision
+// accumulator, which removes the 32-long shift chain of a single decision word.
+template <int KIND, int N>
+__device__ __forceinline__ void acs_quad_c(const float (&m)[64], float (&o)[64], float t0, float t1, float t01,
+                                           uint32_t (&dw)[4])
+{
+    float a0[4], a1[4], df[4];
+#define GR_ACS_IN(K)                                                              \
+    {                                                                             \
+        constexpr int n = N + K, j = n & 31, b = n >> 5, p0 = 2 * j, p1 = 2 * j + 1; \
+        a0[K] = add_tab<KIND, sv_out(p0, b)>(m[p0], t0, t1, t01);                 \
+        a1[K] = add_tab<KIND, sv_out(p1, b)>(m[p1], t0, t1, t01);                 \
+    }
+    GR_ACS_IN(0) GR_ACS_IN(1) GR_ACS_IN(2) GR_ACS_IN(3)
+#undef GR_ACS_IN
+#pragma unroll
+    for (int k = 0; k < 4; k++) df[k] = a0[k] - a1[k];
+#pragma unroll
+    for (int k = 0; k < 4; k++) o[N + k] = fmaxf(a0[k], a1[k]);
+#pragma unroll
+    for (int k = 0; k < 4; k++) dw[k] = __builtin_amdgcn_alignbit(dw[k], __float_as_uint(df[k]), 31);
+}
+
+template <int KIND, int BASE, int... N>
+__device__ __forceinline__ void acs_range4(const float (&m)[64], float (&o)[64], float t0, float t1, float t01,
+                                           uint32_t (&dw)[4], std::integer_sequence<int, N...>)
+{
+    (acs_quad_c<KIND, BASE + 4 * N>(m, o, t0, t1, t01, dw), ...);
+}
+
 template <int KIND, int BASE, int... N>
 __device__ __forceinline__ void acs_range(const float (&m)[64], float (&o)[64], float t0, float t1, float t01,
                                           uint32_t &dw, std::integer_sequence<int, N...>)
 {
-#ifdef GR80211_PLAIN_ACS
-    (acs_one<KIND, BASE + N>(m, o, t0, t1, t01, dw), ...);
-#else
+#ifdef GR80211_ASM_ACS
     (acs_quad<KIND, BASE + 4 * N>(m, o, t0, t1, t01, dw), ...);
+#else
+    (acs_one<KIND, BASE + N>(m, o, t0, t1, t01, dw), ...);
 #endif
 }
 
-// One trellis step for 64 frames.  Survivor bit of state n lands in bit 31-(n&31) of word n>>5.
+// One trellis step for 64 frames.  Survivor bits of states 32w .. 32w+31 go to word w; within a word
+// state n sits at bit DEC_BIT(n) (see dec_bit()).
 template <int KIND>
 __device__ __forceinline__ void acs_step(const float (&m)[64], float (&o)[64], float t0, float t1, uint32_t *dec)
 {
     const float t01 = t1 + t0;
+#if defined(GR80211_ASM_ACS) || defined(GR80211_PLAIN_ACS) || defined(GR80211_CHAIN_ACS)
     uint32_t d0 = 0, d1 = 0;
-#ifdef GR80211_PLAIN_ACS
-    acs_range<KIND, 0>(m, o, t0, t1, t01, d0, std::make_integer_sequence<int, 32>{});
-    acs_range<KIND, 32>(m, o, t0, t1, t01, d1, std::make_integer_sequence<int, 32>{});
-#else
+#ifdef GR80211_ASM_ACS
     acs_range<KIND, 0>(m, o, t0, t1, t01, d0, std::make_integer_sequence<int, 8>{});
     acs_range<KIND, 32>(m, o, t0, t1, t01, d1, std::make_integer_sequence<int, 8>{});
+#else
+    acs_range<KIND, 0>(m, o, t0, t1, t01, d0, std::make_integer_sequence<int, 32>{});
+    acs_range<KIND, 32>(m, o, t0, t1, t01, d1, std::make_integer_sequence<int, 32>{});
 #endif
     dec[0] = d0;
     dec[64] = d1;
+#else
+    uint32_t qa[4] = {0, 0, 0, 0}, qb[4] = {0, 0, 0, 0};
+    acs_range4<KIND, 0>(m, o, t0, t1, t01, qa, std::make_integer_sequence<int, 8>{});
+    acs_range4<KIND, 32>(m, o, t0, t1, t01, qb, std::make_integer_sequence<int, 8>{});
+    // accumulator k holds states k, k+4, ..., k+28 (first in the top bit of its byte)
+    dec[0] = qa[0] | (qa[1] << 8) | (qa[2] << 16) | (qa[3] << 24);
+    dec[64] = qb[0] | (qb[1] << 8) | (qb[2] << 16) | (qb[3] << 24);
+#endif
+}
+
+// Bit position of state n's survivor bit inside its 32-bit decision word.
+__device__ __forceinline__ int dec_bit(int n)
+{
+#if defined(GR80211_ASM_ACS) || defined(GR80211_PLAIN_ACS) || defined(GR80211_CHAIN_ACS)
+    return 31 - (n & 31);
+#else
+    return 8 * (n & 3) + 7 - ((n & 31) >> 2);
+#endif
 }
 
 template <int CR> struct Rate;
@@ -1051,9 +1206,8 @@ __device__ __forceinline__ void period(float (&A)[64], float (&B)[64], const flo
 constexpr int TILE_STRIDE = 65;
 
 template <int CR>
-__device__ __forceinline__ void viterbi_group(const float *__restrict__ llr, const unsigned long long *rowbase,
-                                              const int *rown, int nchunks, uint32_t *__restrict__ dec,
-                                              float *tile, int lane)
+__device__ __forceinline__ void viterbi_group(const float *__restrict__ llr, unsigned long long mybase, int myn,
+                                              int nchunks, uint32_t *__restrict__ dec, float *tile, int lane)
 {
     constexpr int P = Rate<CR>::P, COLS = Rate<CR>::COLS, NPER = Rate<CR>::NPER;
     constexpr int CH = COLS * NPER;    // LLR columns per tile
@@ -1065,12 +1219,23 @@ __device__ __forceinline__ void viterbi_group(const float *__restrict__ llr, con
     for (int ch = 0; ch < nchunks; ch++) {
         __syncthreads();
         const int c0 = ch * CH + lane;
-#pragma unroll 8
+        // 64 rows (frames) x 64 columns, transposed through LDS.  Each row is one LDS-DMA load
+        // (global_load_lds_dword: lane l of the wave writes tile[row][l]), so all 64 are in flight
+        // together and cost no VGPRs while the 128 path-metric registers are live.  Columns past a
+        // frame's last soft bit are clamped to it: they only feed trellis steps after that frame's end.
+#pragma unroll
         for (int r = 0; r < 64; r++) {
-            float v = 0.0f;
-            if (lane < CH && c0 < rown[r]) v = llr[rowbase[r] + (unsigned long long)c0];
-            tile[r * TILE_STRIDE + lane] = v;
+            const unsigned lo = __builtin_amdgcn_readlane((int)(mybase & 0xffffffffull), r);
+            const unsigned hi = __builtin_amdgcn_readlane((int)(mybase >> 32), r);
+            const int nr = __builtin_amdgcn_readlane(myn, r);
+            const unsigned long long base = ((unsigned long long)hi << 32) | lo;
+            int idx = c0 < nr ? c0 : nr - 1;
+            idx = idx < 0 ? 0 : idx;
+            const float *src = llr + base + (unsigned long long)idx;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)(tile + r * TILE_STRIDE), 4, 0, 0);
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         uint32_t *dp = dec + (size_t)ch * STEPS * 128 + lane;
 #pragma unroll 1
@@ -1091,18 +1256,17 @@ __global__ __launch_bounds__(64) void k_viterbi(const float *__restrict__ llr, c
     if (g >= n_groups) return;
     const int lane = threadIdx.x;
     __shared__ float tile[64 * TILE_STRIDE];
-    __shared__ unsigned long long rowbase[64];
-    __shared__ int rown[64];
     const GroupInfo gi = groups[g];
     const int fr = slot_frame[g * 64 + lane];
-    rowbase[lane] = fr >= 0 ? (unsigned long long)info[fr].llr_off : 0ull;
-    rown[lane] = fr >= 0 ? info[fr].total : 0;
+    // a lane without a frame reads element 0 of the arena (always present) and ignores it
+    const int myn = fr >= 0 ? info[fr].total : 0;
+    const unsigned long long mybase = myn > 0 ? (unsigned long long)info[fr].llr_off : 0ull;
     uint32_t *d = dec + gi.dec_off;
     switch (gi.cr) {
-    case CR_12: viterbi_group<CR_12>(llr, rowbase, rown, gi.nchunks, d, tile, lane); break;
-    case CR_23: viterbi_group<CR_23>(llr, rowbase, rown, gi.nchunks, d, tile, lane); break;
-    case CR_34: viterbi_group<CR_34>(llr, rowbase, rown, gi.nchunks, d, tile, lane); break;
-    default: viterbi_group<CR_56>(llr, rowbase, rown, gi.nchunks, d, tile, lane); break;
+    case CR_12: viterbi_group<CR_12>(llr, mybase, myn, gi.nchunks, d, tile, lane); break;
+    case CR_23: viterbi_group<CR_23>(llr, mybase, myn, gi.nchunks, d, tile, lane); break;
+    case CR_34: viterbi_group<CR_34>(llr, mybase, myn, gi.nchunks, d, tile, lane); break;
+    default: viterbi_group<CR_56>(llr, mybase, myn, gi.nchunks, d, tile, lane); break;
     }
 }
 
@@ -1134,22 +1298,63 @@ __global__ __launch_bounds__(64) void k_traceback(const uint32_t *__restrict__ d
     const uint32_t *d = dec + gi.dec_off + lane;
     uint32_t *bw = bitsw + gi.bits_off + lane;
 
-    // ---- traceback from state 0 at step T (lib/decode_impl.cc:282-302)
+    // ---- traceback from state 0 at step T (lib/decode_impl.cc:282-302).  The survivor words do not
+    // depend on the path, so they are fetched into a ring of four register sets: three blocks of
+    // 2*TB coalesced 256-B loads stay in flight while the dependent bit-extract chain walks one.
     {
+        constexpr int TB = 16;
         int s = 0;
         uint32_t acc = 0;
-        for (int t = gi.steps - 1; t >= 0; t--) {
-            const uint32_t w0 = d[(size_t)t * 128], w1 = d[(size_t)t * 128 + 64];
-            if (t == T - 1) s = 0;
-            acc |= (uint32_t)(s >> 5) << (t & 31);  // decoded bit t = newest bit of the state after step t
-            const uint32_t w = (s & 32) ? w1 : w0;
-            const int dbit = (int)((w >> (31 - (s & 31))) & 1u);
-            s = ((s & 31) << 1) | dbit;
-            if ((t & 31) == 0) {
-                bw[(size_t)(t >> 5) * 64] = acc;
-                acc = 0;
-            }
+        uint32_t wa[2 * TB], wb[2 * TB], wc[2 * TB], wd[2 * TB];
+        const int steps = gi.steps;
+        const int nblk = (steps + TB - 1) / TB;
+#define GR_TB_FETCH(W, BLK)                                  \
+    {                                                        \
+        const int thi = steps - 1 - (BLK) * TB;              \
+        _Pragma("unroll") for (int k = 0; k < TB; k++) {     \
+            int t = thi - k;                                 \
+            t = t < 0 ? 0 : t;                               \
+            W[2 * k] = d[(size_t)t * 128];                   \
+            W[2 * k + 1] = d[(size_t)t * 128 + 64];          \
+        }                                                    \
+    }
+#define GR_TB_WALK(W, BLK)                                                                          \
+    {                                                                                               \
+        const int thi = steps - 1 - (BLK) * TB;                                                     \
+        _Pragma("unroll") for (int k = 0; k < TB; k++) {                                            \
+            const int t = thi - k;                                                                  \
+            if (t >= 0) {                                                                           \
+                if (t == T - 1) s = 0;                                                              \
+                acc |= (uint32_t)(s >> 5) << (t & 31); /* bit t = newest bit of the state after step t */ \
+                /* both words are shifted first: selecting between the two array elements would be   \
+                   turned into a run-time array index and push the register sets into scratch */    \
+                const int pos = dec_bit(s);                                                         \
+                const uint32_t b0 = W[2 * k] >> pos, b1 = W[2 * k + 1] >> pos;                      \
+                const int dbit = (int)(((s & 32) ? b1 : b0) & 1u);                                  \
+                s = ((s & 31) << 1) | dbit;                                                         \
+                if ((t & 31) == 0) {                                                                \
+                    bw[(size_t)(t >> 5) * 64] = acc;                                                \
+                    acc = 0;                                                                        \
+                }                                                                                   \
+            }                                                                                       \
+        }                                                                                           \
+    }
+        GR_TB_FETCH(wa, 0)
+        GR_TB_FETCH(wb, 1)
+        GR_TB_FETCH(wc, 2)
+        GR_TB_FETCH(wd, 3)
+        for (int blk = 0; blk < nblk; blk += 4) {
+            GR_TB_WALK(wa, blk)
+            GR_TB_FETCH(wa, blk + 4)
+            GR_TB_WALK(wb, blk + 1)
+            GR_TB_FETCH(wb, blk + 5)
+            GR_TB_WALK(wc, blk + 2)
+            GR_TB_FETCH(wc, blk + 6)
+            GR_TB_WALK(wd, blk + 3)
+            GR_TB_FETCH(wd, blk + 7)
         }
+#undef GR_TB_FETCH
+#undef GR_TB_WALK
     }
     if (fr < 0) return;
     const gr80211_frame_info fi = info[fr];
@@ -1276,10 +1481,18 @@ void launch_desc_to_info(const gr80211_dec_desc *desc, int n, gr80211_frame_info
     hipLaunchKernelGGL(k_desc_to_info, dim3((n + 255) / 256), dim3(256), 0, s, desc, n, info);
 }
 void launch_schedule(gr80211_frame_info *info, int n, int assign_llr, int32_t *slot_frame, int slot_cap,
-                     GroupInfo *groups, int group_cap, SchedTotals *totals, hipStream_t s)
+                     GroupInfo *groups, int group_cap, SchedTotals *totals, uint32_t *ws, unsigned long long *blk_llr,
+                     hipStream_t s)
 {
-    hipLaunchKernelGGL(k_schedule, dim3(1), dim3(1024), 0, s, info, n, assign_llr, slot_frame, slot_cap, groups,
-                       group_cap, totals);
+    const int nblk = (n + SCHED_BLOCK - 1) / SCHED_BLOCK;
+    const int nws = SCHED_BINS + 8;
+    hipLaunchKernelGGL(k_zero_u32, dim3((nws + 255) / 256), dim3(256), 0, s, ws, nws);
+    hipLaunchKernelGGL(k_sched_hist, dim3(nblk), dim3(SCHED_BLOCK), 0, s, info, n, ws, blk_llr);
+    hipLaunchKernelGGL(k_sched_scan, dim3(1), dim3(1024), 0, s, ws, blk_llr, nblk, assign_llr, slot_cap, group_cap,
+                       slot_frame, groups, totals);
+    hipLaunchKernelGGL(k_sched_assign, dim3(nblk), dim3(SCHED_BLOCK), 0, s, info, n, assign_llr, ws, blk_llr,
+                       slot_frame, groups, totals);
+    hipLaunchKernelGGL(k_sched_groups, dim3(1), dim3(1024), 0, s, groups, totals);
 }
 void launch_demod(const void *iq0, const void *iq1, const gr80211_frame_desc *desc, int n,
                   const gr80211_frame_info *info, const void *chan1, const void *chan2, float *llr, hipStream_t s)

@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgr80211_rx.so")
+LIB_PATH = os.environ.get("GR80211_RX_LIB", os.path.join(_HERE, "libgr80211_rx.so"))  # override: A/B builds
 
 ST_NAMES = {0: "ok", 1: "drop_lsig", 2: "drop_len_check", 3: "drop_unsupported", 4: "drop_decode_limit"}
 FLAG_DESC_ON_DEVICE = 1
