@@ -867,20 +867,15 @@ __global__ void k_zero_u32(uint32_t *p, int n)
 // =========================================================================================
 // k_demod: one workgroup (4 waves) per frame, each wave strides over OFDM symbols
 // =========================================================================================
-// Max-log soft demap of one axis after constellation scaling (lib/cloud80211phy.cc:2090-2148).
-__device__ __forceinline__ void axis_llr(float v, int nb, float *o)
+// Max-log soft demap of one axis after constellation scaling (lib/cloud80211phy.cc:2090-2148):
+// o0 = v, o1 = E - |v|, o2 = E/2 - |o1|, o3 = 2 - |o2| with E = 2, 4, 8 for 2, 3, 4 bits per axis.
+__device__ __forceinline__ void axis_llr(float v, int nb, float &o0, float &o1, float &o2, float &o3)
 {
-    o[0] = v;
-    if (nb >= 2) {
-        const float edge = nb == 2 ? 2.0f : nb == 3 ? 4.0f : 8.0f;
-        const float l1 = edge - fabsf(v);
-        o[1] = l1;
-        if (nb >= 3) {
-            const float l2 = edge * 0.5f - fabsf(l1);
-            o[2] = l2;
-            if (nb >= 4) o[3] = 2.0f - fabsf(l2);
-        }
-    }
+    const float edge = nb == 2 ? 2.0f : nb == 3 ? 4.0f : 8.0f;
+    o0 = v;
+    o1 = edge - fabsf(v);
+    o2 = edge * 0.5f - fabsf(o1);
+    o3 = 2.0f - fabsf(o2);
 }
 
 __device__ __forceinline__ float qam_scale(int mod)
@@ -889,18 +884,69 @@ __device__ __forceinline__ float qam_scale(int mod)
          : mod == QAM_64 ? 6.48074069840786f : mod == QAM_256 ? 13.038404810405298f : 1.0f;
 }
 
-__global__ __launch_bounds__(256) void k_demod(const c32 *__restrict__ iq0, const c32 *__restrict__ iq1,
-                                               const gr80211_frame_desc *__restrict__ descs, int n,
-                                               const gr80211_frame_info *__restrict__ info,
-                                               const c32 *__restrict__ chan1, const c32 *__restrict__ chan2,
-                                               float *__restrict__ llr)
+constexpr int DEMOD_WAVES = 4;
+constexpr int DEMOD_STAGE = 832;  // soft bits of one OFDM symbol: 2 streams x 52 tones x 8 bits
+
+// Soft bits of one tone -> their deinterleaved (and stream-deparsed) places in the symbol's LDS stage.
+__device__ __forceinline__ void put_llrs(float *stage, c32 q, int mod, float scale, int nb, int nax, int jd,
+                                         const int16_t *map, int ss, int sblk, bool two)
+{
+    if (mod != QAM_BPSK) q = cmulf(q, scale);
+    float li0, li1, li2, li3, lq0, lq1, lq2, lq3;
+    axis_llr(q.x, nax, li0, li1, li2, li3);
+    axis_llr(q.y, nax, lq0, lq1, lq2, lq3);
+    const int base = jd * nb;
+#define GR_PUT(IDX, VAL)                                                                       \
+    {                                                                                          \
+        int k = map[base + (IDX)];                                                             \
+        if (two) k = (k / sblk) * 2 * sblk + ss * sblk + (k % sblk); /* lib/cloud80211phy.cc:2442-2451 */ \
+        stage[k] = (VAL);                                                                      \
+    }
+    GR_PUT(0, li0)
+    if (nb >= 2) {
+        GR_PUT(nax, lq0)
+        if (nax >= 2) {
+            GR_PUT(1, li1)
+            GR_PUT(nax + 1, lq1)
+            if (nax >= 3) {
+                GR_PUT(2, li2)
+                GR_PUT(nax + 2, lq2)
+                if (nax >= 4) {
+                    GR_PUT(3, li3)
+                    GR_PUT(nax + 3, lq3)
+                }
+            }
+        }
+    }
+#undef GR_PUT
+}
+
+// The wave's staged symbol -> the frame's LLR run, 16 bytes per lane (runs are 16-byte aligned:
+// every frame's soft-bit count is a multiple of 4).
+__device__ __forceinline__ void flush_stage(const float *stage, float *dst, int ncbps, int lane)
+{
+    __builtin_amdgcn_wave_barrier();
+    for (int i = lane * 4; i < ncbps; i += 256) {
+        const float4 v = *reinterpret_cast<const float4 *>(stage + i);
+        *reinterpret_cast<float4 *>(dst + i) = v;
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+__global__ __launch_bounds__(64 * DEMOD_WAVES) void k_demod(const c32 *__restrict__ iq0, const c32 *__restrict__ iq1,
+                                                            const gr80211_frame_desc *__restrict__ descs, int n,
+                                                            const gr80211_frame_info *__restrict__ info,
+                                                            const c32 *__restrict__ chan1, const c32 *__restrict__ chan2,
+                                                            float *__restrict__ llr)
 {
     const int f = blockIdx.x;
     if (f >= n) return;
     const int st = info[f].status;
     if (!(st == GR80211_ST_OK || st == GR80211_ST_DROP_DECODE_LIMIT)) return;
+    __shared__ __attribute__((aligned(16))) float s_stage[DEMOD_WAVES][DEMOD_STAGE];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int bin = brev6(lane);
+    float *stage = s_stage[wave];
     const gr80211_frame_info fi = info[f];
     const gr80211_frame_desc d = descs[f];
     const c32 *in0 = iq0 + d.sync_off;
@@ -909,14 +955,14 @@ __global__ __launch_bounds__(256) void k_demod(const c32 *__restrict__ iq0, cons
     int nvalid = fi.nsamp;
     if (nvalid > (int)d.n_avail - 224) nvalid = (int)d.n_avail - 224;
 
-    const int fmt = fi.format, nss = fi.nSS, nb = fi.nBPSCS, ncbps = fi.nCBPS;
+    const int fmt = fi.format, nss = fi.nSS, nb = fi.nBPSCS, ncbps = fi.nCBPS, mod = fi.mod;
     const bool legacy = fmt == GR80211_F_L;
     const bool used = legacy ? (c_tab.ltf_l[bin] != 0.0f) : (c_tab.ltf_nl[bin] != 0.0f);
     const bool pil = is_pilot_bin(bin);
     const int jd = legacy ? c_tab.data_idx_l[bin] : c_tab.data_idx_nl[bin];
     const int pslot = bin == 43 ? 0 : bin == 57 ? 1 : bin == 7 ? 2 : 3;
     const int didx = nb == 1 ? 0 : nb == 2 ? 1 : nb == 4 ? 2 : nb == 6 ? 3 : 4;
-    const float scale = qam_scale(fi.mod);
+    const float scale = qam_scale(mod);
     const int nax = nb == 1 ? 1 : nb / 2;  // bits per axis (BPSK: one bit, I axis only)
     float *out = llr + fi.llr_off;
     const int pp0 = legacy ? 1 : fmt == GR80211_F_HT ? 3 : 4;
@@ -924,34 +970,21 @@ __global__ __launch_bounds__(256) void k_demod(const c32 *__restrict__ iq0, cons
     if (nss == 1) {
         const c32 h = chan1[(size_t)f * 64 + bin];
         const int16_t *map = legacy ? c_tab.deint_l[didx] : c_tab.deint_nl[didx];
-        const float base[4] = {1.0f, 1.0f, 1.0f, -1.0f};  // PILOT_L = PILOT_HT_1 = PILOT_VHT
-        for (int sym = wave; sym < fi.nSym; sym += 4) {
+        for (int sym = wave; sym < fi.nSym; sym += DEMOD_WAVES) {
             const int off = fi.data_off + sym * fi.nSymSamp;
             const c32 F = wave_fft64(load_samp(in0, off + SHIFT + lane, nvalid, rad), lane);
             c32 e = mk(0.0f, 0.0f);
             if (used) e = cdiv(F, h);
-            // pilot term of this lane's tone: sig * pilot * polarity (lib/demod_impl.cc:426-430)
+            // pilot term of this lane's tone: sig * pilot * polarity (lib/demod_impl.cc:426-430);
+            // base pattern {1,1,1,-1}, rotated one place per symbol for HT/VHT
             const float pp = c_tab.pilot_p[(pp0 + sym) % 127];
-            const float pv = legacy ? base[pslot] : base[(pslot + sym) & 3];
+            const int pr = legacy ? pslot : ((pslot + sym) & 3);
+            const float pv = pr == 3 ? -1.0f : 1.0f;
             const c32 u = cmulf(cmulf(e, pv), pp);
             const c32 ps = cconj(cadd(cadd(cadd(shfl_c(u, LN7), shfl_c(u, LN21)), shfl_c(u, LN43)), shfl_c(u, LN57)));
             const float pa = cabs32(ps);
-            c32 q = cdivf(cmul(e, ps), pa);
-            if (jd >= 0) {
-                if (fi.mod != QAM_BPSK) q = cmulf(q, scale);
-                float li[4], lq[4];
-                axis_llr(q.x, nax, li);
-                axis_llr(q.y, nax, lq);
-                float *o = out + (size_t)sym * ncbps;
-                if (nb == 1) {
-                    o[map[jd]] = li[0];
-                } else {
-                    for (int b = 0; b < nax; b++) {
-                        o[map[jd * nb + b]] = li[b];
-                        o[map[jd * nb + nax + b]] = lq[b];
-                    }
-                }
-            }
+            if (jd >= 0) put_llrs(stage, cdivf(cmul(e, ps), pa), mod, scale, nb, nax, jd, map, 0, 1, false);
+            flush_stage(stage, out + (size_t)sym * ncbps, ncbps, lane);
         }
     } else {
         // two spatial streams on two antennas (lib/demod2_impl.cc:504-550, 586-628)
@@ -962,13 +995,10 @@ __global__ __launch_bounds__(256) void k_demod(const c32 *__restrict__ iq0, cons
         const c32 pl1 = pil ? c2[512 + pslot] : mk(0.0f, 0.0f);
         const c32 pl2 = pil ? c2[516 + pslot] : mk(0.0f, 0.0f);
         const bool vht = fmt == GR80211_F_VHT;
-        const float b1[4] = {1.0f, 1.0f, 1.0f, -1.0f};    // PILOT_VHT
-        const float bh1[4] = {1.0f, 1.0f, -1.0f, -1.0f};  // PILOT_HT_2_1
-        const float bh2[4] = {1.0f, -1.0f, -1.0f, 1.0f};  // PILOT_HT_2_2
         const int16_t *map1 = c_tab.deint_nl[didx];
         const int16_t *map2 = c_tab.deint_nl2[didx];
         const int sblk = nb / 2 > 1 ? nb / 2 : 1;  // stream parser block
-        for (int sym = wave; sym < fi.nSym; sym += 4) {
+        for (int sym = wave; sym < fi.nSym; sym += DEMOD_WAVES) {
             const int off = fi.data_off + sym * fi.nSymSamp;
             const c32 F1 = wave_fft64(load_samp(in0, off + SHIFT + lane, nvalid, rad), lane);
             const c32 F2 = wave_fft64(load_samp(in1, off + SHIFT + lane, nvalid, rad), lane);
@@ -976,8 +1006,9 @@ __global__ __launch_bounds__(256) void k_demod(const c32 *__restrict__ iq0, cons
             if (used) zf2(F1, F2, h, hi, s1, s2);
             const float pp = c_tab.pilot_p[(pp0 + sym) % 127];
             const int pr = (pslot + sym) & 3;
-            const float pv1 = vht ? b1[pr] : bh1[pr];
-            const float pv2 = vht ? b1[pr] : bh2[pr];
+            // PILOT_VHT {1,1,1,-1} on both streams; PILOT_HT_2_1 {1,1,-1,-1}, PILOT_HT_2_2 {1,-1,-1,1}
+            const float pv1 = vht ? (pr == 3 ? -1.0f : 1.0f) : (pr >= 2 ? -1.0f : 1.0f);
+            const float pv2 = vht ? (pr == 3 ? -1.0f : 1.0f) : ((pr == 1 || pr == 2) ? -1.0f : 1.0f);
             const c32 u1 = cmul(cmulf(cmulf(s1, pv1), pp), pl1);
             const c32 u2 = cmul(cmulf(cmulf(s2, pv2), pp), pl2);
             c32 acc = shfl_c(u1, LN7);
@@ -991,24 +1022,10 @@ __global__ __launch_bounds__(256) void k_demod(const c32 *__restrict__ iq0, cons
             const c32 ps = cconj(acc);
             const float pa = cabs32(ps);
             if (jd >= 0) {
-                float *o = out + (size_t)sym * ncbps;
-#pragma unroll
-                for (int ss = 0; ss < 2; ss++) {
-                    c32 q = cdivf(cmul(ss ? s2 : s1, ps), pa);
-                    if (fi.mod != QAM_BPSK) q = cmulf(q, scale);
-                    float li[4], lq[4];
-                    axis_llr(q.x, nax, li);
-                    axis_llr(q.y, nax, lq);
-                    const int16_t *map = ss ? map2 : map1;
-                    const int nbits = nb == 1 ? 1 : nb;
-                    for (int b = 0; b < nbits; b++) {
-                        const float v = nb == 1 ? li[0] : (b < nax ? li[b] : lq[b - nax]);
-                        const int k = map[jd * nb + b];  // position in this stream's deinterleaved block
-                        // stream de-parser: blocks of sblk bits alternate (lib/cloud80211phy.cc:2442-2451)
-                        o[(k / sblk) * 2 * sblk + ss * sblk + (k % sblk)] = v;
-                    }
-                }
+                put_llrs(stage, cdivf(cmul(s1, ps), pa), mod, scale, nb, nax, jd, map1, 0, sblk, true);
+                put_llrs(stage, cdivf(cmul(s2, ps), pa), mod, scale, nb, nax, jd, map2, 1, sblk, true);
             }
+            flush_stage(stage, out + (size_t)sym * ncbps, ncbps, lane);
         }
     }
 }
