@@ -26,6 +26,7 @@ struct gr80211_ctx {
     Buf desc, ddesc, info, chan1, chan2, llr, slot_frame, groups, dec, bitsw, totals_d, sched_ws, blk_llr;
     SchedTotals *totals_h = nullptr;  // pinned
     bool profiling = false;
+    bool split_decode = false;  // GR80211_SPLIT_DECODE=1: forward pass and traceback as two kernels
     hipEvent_t ev[7] = {};
     float ms[6] = {};
 };
@@ -149,12 +150,20 @@ int run_decode_stages(gr80211_ctx *c, hipStream_t s, int n, bool from_iq, const 
         if (tot.n_groups > 0) {
             if ((rc = ensure(c, c->dec, (size_t)(tot.dec_words + 128) * sizeof(uint32_t)))) return rc;
             if ((rc = ensure(c, c->bitsw, (size_t)(tot.bits_words + 64) * sizeof(uint32_t)))) return rc;
-            launch_viterbi(llr, info, (const int32_t *)c->slot_frame.p, (const GroupInfo *)c->groups.p, tot.n_groups,
-                           (uint32_t *)c->dec.p, s);
-            mark(c, 4, s);
-            launch_traceback((const uint32_t *)c->dec.p, info, (const int32_t *)c->slot_frame.p,
-                             (const GroupInfo *)c->groups.p, tot.n_groups, (uint32_t *)c->bitsw.p, d_out, out_stride,
-                             d_out_len, d_n_pdu, d_bits, bits_stride, s);
+            if (c->split_decode) {
+                launch_viterbi(llr, info, (const int32_t *)c->slot_frame.p, (const GroupInfo *)c->groups.p,
+                               tot.n_groups, (uint32_t *)c->dec.p, s);
+                mark(c, 4, s);
+                launch_traceback((const uint32_t *)c->dec.p, info, (const int32_t *)c->slot_frame.p,
+                                 (const GroupInfo *)c->groups.p, tot.n_groups, (uint32_t *)c->bitsw.p, d_out,
+                                 out_stride, d_out_len, d_n_pdu, d_bits, bits_stride, s);
+            } else {
+                // one kernel: the timing slot of the forward pass then covers the traceback as well
+                launch_decode(llr, info, (const int32_t *)c->slot_frame.p, (const GroupInfo *)c->groups.p,
+                              tot.n_groups, (uint32_t *)c->dec.p, (uint32_t *)c->bitsw.p, d_out, out_stride,
+                              d_out_len, d_n_pdu, d_bits, bits_stride, s);
+                mark(c, 4, s);
+            }
         } else {
             mark(c, 4, s);
         }
@@ -214,6 +223,7 @@ int gr80211_create(gr80211_ctx **out, int device)
     if (hipSetDevice(device) != hipSuccess) return GR80211_ERR_HIP;
     gr80211_ctx *c = new gr80211_ctx();
     c->device = device;
+    if (const char *e = getenv("GR80211_SPLIT_DECODE")) c->split_decode = e[0] == '1';
     {
         std::lock_guard<std::mutex> lk(g_upload_mutex);
         if (!g_uploaded[device]) {

@@ -887,38 +887,52 @@ __device__ __forceinline__ float qam_scale(int mod)
 constexpr int DEMOD_WAVES = 4;
 constexpr int DEMOD_STAGE = 832;  // soft bits of one OFDM symbol: 2 streams x 52 tones x 8 bits
 
-// Soft bits of one tone -> their deinterleaved (and stream-deparsed) places in the symbol's LDS stage.
-__device__ __forceinline__ void put_llrs(float *stage, c32 q, int mod, float scale, int nb, int nax, int jd,
-                                         const int16_t *map, int ss, int sblk, bool two)
+// Places of one tone's soft bits in the symbol's LDS stage after deinterleaving (and, for two
+// streams, stream de-parsing, lib/cloud80211phy.cc:2442-2451): kI[i] for bit i of the I axis,
+// kQ[i] for bit i of the Q axis.  They do not change from symbol to symbol.
+__device__ __forceinline__ void tone_slots(int (&kI)[4], int (&kQ)[4], const int16_t *map, int jd, int nb, int nax,
+                                           int ss, int sblk, bool two)
+{
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        int vi = 0, vq = 0;
+        if (jd >= 0 && i < nax) {
+            vi = map[jd * nb + i];
+            if (two) vi = (vi / sblk) * 2 * sblk + ss * sblk + (vi % sblk);
+            if (nb >= 2) {
+                vq = map[jd * nb + nax + i];
+                if (two) vq = (vq / sblk) * 2 * sblk + ss * sblk + (vq % sblk);
+            }
+        }
+        kI[i] = vi;
+        kQ[i] = vq;
+    }
+}
+
+// Soft bits of one tone -> the symbol's LDS stage.
+__device__ __forceinline__ void put_llrs(float *stage, c32 q, int mod, float scale, int nb, int nax,
+                                         const int (&kI)[4], const int (&kQ)[4])
 {
     if (mod != QAM_BPSK) q = cmulf(q, scale);
     float li0, li1, li2, li3, lq0, lq1, lq2, lq3;
     axis_llr(q.x, nax, li0, li1, li2, li3);
     axis_llr(q.y, nax, lq0, lq1, lq2, lq3);
-    const int base = jd * nb;
-#define GR_PUT(IDX, VAL)                                                                       \
-    {                                                                                          \
-        int k = map[base + (IDX)];                                                             \
-        if (two) k = (k / sblk) * 2 * sblk + ss * sblk + (k % sblk); /* lib/cloud80211phy.cc:2442-2451 */ \
-        stage[k] = (VAL);                                                                      \
-    }
-    GR_PUT(0, li0)
+    stage[kI[0]] = li0;
     if (nb >= 2) {
-        GR_PUT(nax, lq0)
+        stage[kQ[0]] = lq0;
         if (nax >= 2) {
-            GR_PUT(1, li1)
-            GR_PUT(nax + 1, lq1)
+            stage[kI[1]] = li1;
+            stage[kQ[1]] = lq1;
             if (nax >= 3) {
-                GR_PUT(2, li2)
-                GR_PUT(nax + 2, lq2)
+                stage[kI[2]] = li2;
+                stage[kQ[2]] = lq2;
                 if (nax >= 4) {
-                    GR_PUT(3, li3)
-                    GR_PUT(nax + 3, lq3)
+                    stage[kI[3]] = li3;
+                    stage[kQ[3]] = lq3;
                 }
             }
         }
     }
-#undef GR_PUT
 }
 
 // The wave's staged symbol -> the frame's LLR run, 16 bytes per lane (runs are 16-byte aligned:
@@ -944,7 +958,8 @@ __global__ __launch_bounds__(64 * DEMOD_WAVES) void k_demod(const c32 *__restric
     const int st = info[f].status;
     if (!(st == GR80211_ST_OK || st == GR80211_ST_DROP_DECODE_LIMIT)) return;
     __shared__ __attribute__((aligned(16))) float s_stage[DEMOD_WAVES][DEMOD_STAGE];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // symbol counters stay scalar
     const int bin = brev6(lane);
     float *stage = s_stage[wave];
     const gr80211_frame_info fi = info[f];
@@ -970,9 +985,14 @@ __global__ __launch_bounds__(64 * DEMOD_WAVES) void k_demod(const c32 *__restric
     if (nss == 1) {
         const c32 h = chan1[(size_t)f * 64 + bin];
         const int16_t *map = legacy ? c_tab.deint_l[didx] : c_tab.deint_nl[didx];
+        int kI[4], kQ[4];
+        tone_slots(kI, kQ, map, jd, nb, nax, 0, 1, false);
+        c32 xn = load_samp(in0, fi.data_off + wave * fi.nSymSamp + SHIFT + lane, nvalid, rad);
         for (int sym = wave; sym < fi.nSym; sym += DEMOD_WAVES) {
-            const int off = fi.data_off + sym * fi.nSymSamp;
-            const c32 F = wave_fft64(load_samp(in0, off + SHIFT + lane, nvalid, rad), lane);
+            const c32 x = xn;
+            if (sym + DEMOD_WAVES < fi.nSym)  // next symbol's samples travel while this one is worked on
+                xn = load_samp(in0, fi.data_off + (sym + DEMOD_WAVES) * fi.nSymSamp + SHIFT + lane, nvalid, rad);
+            const c32 F = wave_fft64(x, lane);
             c32 e = mk(0.0f, 0.0f);
             if (used) e = cdiv(F, h);
             // pilot term of this lane's tone: sig * pilot * polarity (lib/demod_impl.cc:426-430);
@@ -983,7 +1003,7 @@ __global__ __launch_bounds__(64 * DEMOD_WAVES) void k_demod(const c32 *__restric
             const c32 u = cmulf(cmulf(e, pv), pp);
             const c32 ps = cconj(cadd(cadd(cadd(shfl_c(u, LN7), shfl_c(u, LN21)), shfl_c(u, LN43)), shfl_c(u, LN57)));
             const float pa = cabs32(ps);
-            if (jd >= 0) put_llrs(stage, cdivf(cmul(e, ps), pa), mod, scale, nb, nax, jd, map, 0, 1, false);
+            if (jd >= 0) put_llrs(stage, cdivf(cmul(e, ps), pa), mod, scale, nb, nax, kI, kQ);
             flush_stage(stage, out + (size_t)sym * ncbps, ncbps, lane);
         }
     } else {
@@ -998,6 +1018,9 @@ __global__ __launch_bounds__(64 * DEMOD_WAVES) void k_demod(const c32 *__restric
         const int16_t *map1 = c_tab.deint_nl[didx];
         const int16_t *map2 = c_tab.deint_nl2[didx];
         const int sblk = nb / 2 > 1 ? nb / 2 : 1;  // stream parser block
+        int kI1[4], kQ1[4], kI2[4], kQ2[4];
+        tone_slots(kI1, kQ1, map1, jd, nb, nax, 0, sblk, true);
+        tone_slots(kI2, kQ2, map2, jd, nb, nax, 1, sblk, true);
         for (int sym = wave; sym < fi.nSym; sym += DEMOD_WAVES) {
             const int off = fi.data_off + sym * fi.nSymSamp;
             const c32 F1 = wave_fft64(load_samp(in0, off + SHIFT + lane, nvalid, rad), lane);
@@ -1022,8 +1045,8 @@ __global__ __launch_bounds__(64 * DEMOD_WAVES) void k_demod(const c32 *__restric
             const c32 ps = cconj(acc);
             const float pa = cabs32(ps);
             if (jd >= 0) {
-                put_llrs(stage, cdivf(cmul(s1, ps), pa), mod, scale, nb, nax, jd, map1, 0, sblk, true);
-                put_llrs(stage, cdivf(cmul(s2, ps), pa), mod, scale, nb, nax, jd, map2, 1, sblk, true);
+                put_llrs(stage, cdivf(cmul(s1, ps), pa), mod, scale, nb, nax, kI1, kQ1);
+                put_llrs(stage, cdivf(cmul(s2, ps), pa), mod, scale, nb, nax, kI2, kQ2);
             }
             flush_stage(stage, out + (size_t)sym * ncbps, ncbps, lane);
         }
@@ -1295,22 +1318,13 @@ __device__ __forceinline__ uint32_t crc_byte(uint32_t c, uint32_t byte, const ui
     return tab[(c ^ byte) & 0xff] ^ (c >> 8);
 }
 
-__global__ __launch_bounds__(64) void k_traceback(const uint32_t *__restrict__ dec, const gr80211_frame_info *__restrict__ info,
-                                                  const int32_t *__restrict__ slot_frame,
-                                                  const GroupInfo *__restrict__ groups, int n_groups,
-                                                  uint32_t *__restrict__ bitsw, uint8_t *__restrict__ out, int out_stride,
-                                                  int32_t *__restrict__ out_len, int32_t *__restrict__ n_pdu,
-                                                  uint8_t *__restrict__ bits_out, int bits_stride)
+// One group's traceback and packet assembly; s_crc is the CRC-32 byte table in LDS.
+__device__ __forceinline__ void traceback_group(const uint32_t *__restrict__ dec, const gr80211_frame_info *__restrict__ info,
+                                                const GroupInfo &gi, const int fr, const int lane, const uint32_t *s_crc,
+                                                uint32_t *__restrict__ bitsw, uint8_t *__restrict__ out, int out_stride,
+                                                int32_t *__restrict__ out_len, int32_t *__restrict__ n_pdu,
+                                                uint8_t *__restrict__ bits_out, int bits_stride)
 {
-    const int g = blockIdx.x;
-    if (g >= n_groups) return;
-    const int lane = threadIdx.x;
-    __shared__ uint32_t s_crc[256];
-    for (int i = lane; i < 256; i += 64) s_crc[i] = c_tab.crc[i];
-    __syncthreads();
-
-    const GroupInfo gi = groups[g];
-    const int fr = slot_frame[g * 64 + lane];
     const int T = fr >= 0 ? info[fr].trellis : 0;
     const uint32_t *d = dec + gi.dec_off + lane;
     uint32_t *bw = bitsw + gi.bits_off + lane;
@@ -1478,6 +1492,61 @@ __global__ __launch_bounds__(64) void k_traceback(const uint32_t *__restrict__ d
     n_pdu[fr] = npdu;
 }
 
+__global__ __launch_bounds__(64) void k_traceback(const uint32_t *__restrict__ dec, const gr80211_frame_info *__restrict__ info,
+                                                  const int32_t *__restrict__ slot_frame,
+                                                  const GroupInfo *__restrict__ groups, int n_groups,
+                                                  uint32_t *__restrict__ bitsw, uint8_t *__restrict__ out, int out_stride,
+                                                  int32_t *__restrict__ out_len, int32_t *__restrict__ n_pdu,
+                                                  uint8_t *__restrict__ bits_out, int bits_stride)
+{
+    const int g = blockIdx.x;
+    if (g >= n_groups) return;
+    const int lane = threadIdx.x;
+    __shared__ uint32_t s_crc[256];
+    for (int i = lane; i < 256; i += 64) s_crc[i] = c_tab.crc[i];
+    __syncthreads();
+    const GroupInfo gi = groups[g];
+    const int fr = slot_frame[g * 64 + lane];
+    traceback_group(dec, info, gi, fr, lane, s_crc, bitsw, out, out_stride, out_len, n_pdu, bits_out, bits_stride);
+}
+
+// =========================================================================================
+// k_decode: Viterbi forward pass and traceback of one group in one wave.  A wave that finishes its
+// trellis early (it had a SIMD to itself, or a short group) walks its survivors back while other
+// waves still run the add-compare-select recursion, so the memory-bound walk hides behind the
+// VALU-bound recursion instead of following it as a second kernel.
+// =========================================================================================
+__global__ __launch_bounds__(64) void k_decode(const float *__restrict__ llr, const gr80211_frame_info *__restrict__ info,
+                                               const int32_t *__restrict__ slot_frame,
+                                               const GroupInfo *__restrict__ groups, int n_groups,
+                                               uint32_t *__restrict__ dec, uint32_t *__restrict__ bitsw,
+                                               uint8_t *__restrict__ out, int out_stride, int32_t *__restrict__ out_len,
+                                               int32_t *__restrict__ n_pdu, uint8_t *__restrict__ bits_out, int bits_stride)
+{
+    const int g = blockIdx.x;
+    if (g >= n_groups) return;
+    const int lane = threadIdx.x;
+    __shared__ float tile[64 * TILE_STRIDE];
+    const GroupInfo gi = groups[g];
+    const int fr = slot_frame[g * 64 + lane];
+    const int myn = fr >= 0 ? info[fr].total : 0;
+    const unsigned long long mybase = myn > 0 ? (unsigned long long)info[fr].llr_off : 0ull;
+    uint32_t *d = dec + gi.dec_off;
+    switch (gi.cr) {
+    case CR_12: viterbi_group<CR_12>(llr, mybase, myn, gi.nchunks, d, tile, lane); break;
+    case CR_23: viterbi_group<CR_23>(llr, mybase, myn, gi.nchunks, d, tile, lane); break;
+    case CR_34: viterbi_group<CR_34>(llr, mybase, myn, gi.nchunks, d, tile, lane); break;
+    default: viterbi_group<CR_56>(llr, mybase, myn, gi.nchunks, d, tile, lane); break;
+    }
+    // every lane reads back only survivor words it stored itself; drain the stores first
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    uint32_t *s_crc = reinterpret_cast<uint32_t *>(tile);  // the LLR tile is dead from here on
+    for (int i = lane; i < 256; i += 64) s_crc[i] = c_tab.crc[i];
+    __syncthreads();
+    traceback_group(dec, info, gi, fr, lane, s_crc, bitsw, out, out_stride, out_len, n_pdu, bits_out, bits_stride);
+}
+
 __global__ void k_clear_outputs(int32_t *a, int32_t *b, int n)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1527,6 +1596,13 @@ void launch_traceback(const uint32_t *dec, const gr80211_frame_info *info, const
                       int32_t *out_len, int32_t *n_pdu, uint8_t *bits_out, int bits_stride, hipStream_t s)
 {
     hipLaunchKernelGGL(k_traceback, dim3(n_groups), dim3(64), 0, s, dec, info, slot_frame, groups, n_groups, bitsw,
+                       out, out_stride, out_len, n_pdu, bits_out, bits_stride);
+}
+void launch_decode(const float *llr, const gr80211_frame_info *info, const int32_t *slot_frame,
+                   const GroupInfo *groups, int n_groups, uint32_t *dec, uint32_t *bitsw, uint8_t *out, int out_stride,
+                   int32_t *out_len, int32_t *n_pdu, uint8_t *bits_out, int bits_stride, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_decode, dim3(n_groups), dim3(64), 0, s, llr, info, slot_frame, groups, n_groups, dec, bitsw,
                        out, out_stride, out_len, n_pdu, bits_out, bits_stride);
 }
 void launch_clear_outputs(int32_t *out_len, int32_t *n_pdu, int n, hipStream_t s)
