@@ -147,7 +147,9 @@ int gr80211_copy_d2h(gr80211_ctx *ctx, void *h_dst, const void *d_src, size_t by
 
 /*
  * Timing of the last batch call, measured with HIP events on the stream the kernels ran on.
- * ms[0]=preamble, [1]=schedule, [2]=demod, [3]=viterbi forward, [4]=traceback+assemble, [5]=whole call.
+ * ms[0]=preamble, [1]=schedule, [2]=demod, [3]=decode (Viterbi forward pass + traceback + assembly, one kernel),
+ * [4]=0 (traceback + assembly alone when the environment variable GR80211_SPLIT_DECODE=1 selects the two-kernel
+ * form, [3] then being the forward pass alone), [5]=whole call.
  * Only recorded when profiling is switched on (costs one stream synchronisation per call).
  */
 int gr80211_set_profiling(gr80211_ctx *ctx, int on);
