@@ -1075,78 +1075,24 @@ __device__ __forceinline__ float add_tab(float m, float t0, float t1, float t01)
     }
 }
 
-template <int KIND, int N>
-__device__ __forceinline__ void acs_one(const float (&m)[64], float (&o)[64], float t0, float t1, float t01, uint32_t &dw)
-{
-    constexpr int j = N & 31, b = N >> 5, p0 = 2 * j, p1 = 2 * j + 1;
-    constexpr int o0 = sv_out(p0, b), o1 = sv_out(p1, b);
-    const float a0 = add_tab<KIND, o0>(m[p0], t0, t1, t01);
-    const float a1 = add_tab<KIND, o1>(m[p1], t0, t1, t01);
-#if defined(GR80211_PLAIN_ACS)
-    const bool g = a1 > a0;  // strict: ties keep the even predecessor (lib/decode_impl.cc:248-258)
-    o[N] = g ? a1 : a0;
-    dw = (dw << 1) | (g ? 1u : 0u);
-#else
-    // Register-only form of "a1 > a0 ? a1 : a0" plus survivor bit, three VALU instructions and no
-    // scalar mask: the metric is max(a0, a1); the decision is the sign of a0 - a1, which is set
-    // exactly when a1 > a0 (two distinct floats never subtract to zero with subnormals enabled, and
-    // a tie gives +0, i.e. the even predecessor as the reference's strict '>' does,
-    // lib/decode_impl.cc:248-258); v_alignbit shifts it into the decision word.
-    const float diff = a0 - a1;
-    o[N] = fmaxf(a0, a1);
-    dw = __builtin_amdgcn_alignbit(dw, __float_as_uint(diff), 31);
-#endif
-}
-
-// Four add-compare-select updates in one hand-scheduled block: 4 compares into scalar masks, 4
-// selects, 4 add-with-carry that shift each survivor bit into the decision word.  Keeping the
-// compares three instructions ahead of their first use covers the VALU-writes-SGPR wait states,
-// so no s_nop is needed (the compiler pads its own cmp/cndmask pairs with s_nop on gfx950).
-template <int KIND, int N>
-__device__ __forceinline__ void acs_quad(const float (&m)[64], float (&o)[64], float t0, float t1, float t01, uint32_t &dw)
-{
-    float a0[4], a1[4];
-#define GR_ACS_IN(K)                                                              \
-    {                                                                             \
-        constexpr int n = N + K, j = n & 31, b = n >> 5, p0 = 2 * j, p1 = 2 * j + 1; \
-        a0[K] = add_tab<KIND, sv_out(p0, b)>(m[p0], t0, t1, t01);                 \
-        a1[K] = add_tab<KIND, sv_out(p1, b)>(m[p1], t0, t1, t01);                 \
-    }
-    GR_ACS_IN(0) GR_ACS_IN(1) GR_ACS_IN(2) GR_ACS_IN(3)
-#undef GR_ACS_IN
-    float r0, r1, r2, r3;
-    unsigned long long c0, c1, c2, c3, cy;
-    asm("v_cmp_gt_f32_e64 %[c0], %[b0], %[a0]\n\t"
-        "v_cmp_gt_f32_e64 %[c1], %[b1], %[a1]\n\t"
-        "v_cmp_gt_f32_e64 %[c2], %[b2], %[a2]\n\t"
-        "v_cmp_gt_f32_e64 %[c3], %[b3], %[a3]\n\t"
-        "v_cndmask_b32_e64 %[r0], %[a0], %[b0], %[c0]\n\t"
-        "v_cndmask_b32_e64 %[r1], %[a1], %[b1], %[c1]\n\t"
-        "v_cndmask_b32_e64 %[r2], %[a2], %[b2], %[c2]\n\t"
-        "v_cndmask_b32_e64 %[r3], %[a3], %[b3], %[c3]\n\t"
-        "v_addc_co_u32_e64 %[dw], %[cy], %[dw], %[dw], %[c0]\n\t"
-        "v_addc_co_u32_e64 %[dw], %[cy], %[dw], %[dw], %[c1]\n\t"
-        "v_addc_co_u32_e64 %[dw], %[cy], %[dw], %[dw], %[c2]\n\t"
-        "v_addc_co_u32_e64 %[dw], %[cy], %[dw], %[dw], %[c3]"
-        : [r0] "=&v"(r0), [r1] "=&v"(r1), [r2] "=&v"(r2), [r3] "=&v"(r3), [dw] "+v"(dw), [c0] "=&s"(c0),
-          [c1] "=&s"(c1), [c2] "=&s"(c2), [c3] "=&s"(c3), [cy] "=&s"(cy)
-        : [a0] "v"(a0[0]), [b0] "v"(a1[0]), [a1] "v"(a0[1]), [b1] "v"(a1[1]), [a2] "v"(a0[2]), [b2] "v"(a1[2]),
-          [a3] "v"(a0[3]), [b3] "v"(a1[3]));
-    o[N] = r0; o[N + 1] = r1; o[N + 2] = r2; o[N + 3] = r3;
-}
-
-// Four state updates written phase by phase (adds, subtracts, maxima, decision shifts) so that no
+// Four state updates (states N, N+8, N+16, N+24) written phase by phase (adds, subtracts, maxima, decision shifts) so that no
 // instruction sits next to the one it depends on: on gfx950 a dependent VALU pair costs ~9.5 cycles
-// against ~4.3 for independent issue from one wave.  Each of the four states feeds its own decision
+// against ~4.3 for independent issue from one wave.
+//
+// Register-only form of the reference's "a1 > a0 ? a1 : a0" plus survivor bit (lib/decode_impl.cc:248-258),
+// three VALU instructions and no scalar mask: the metric is max(a0, a1); the decision is the sign of
+// a0 - a1, which is set exactly when a1 > a0 (two distinct floats never subtract to zero with
+// subnormals enabled, and a tie gives +0, i.e. the even predecessor as the strict '>' does);
+// v_alignbit shifts it into a decision accumulator.  Each of the four states feeds its own
 // accumulator, which removes the 32-long shift chain of a single decision word.
 template <int KIND, int N>
-__device__ __forceinline__ void acs_quad_c(const float (&m)[64], float (&o)[64], float t0, float t1, float t01,
-                                           uint32_t (&dw)[4])
+__device__ __forceinline__ void acs_quad(const float (&m)[64], float (&o)[64], float t0, float t1, float t01,
+                                         uint32_t (&dw)[4])
 {
     float a0[4], a1[4], df[4];
 #define GR_ACS_IN(K)                                                              \
     {                                                                             \
-        constexpr int n = N + K, j = n & 31, b = n >> 5, p0 = 2 * j, p1 = 2 * j + 1; \
+        constexpr int n = N + 8 * K, j = n & 31, b = n >> 5, p0 = 2 * j, p1 = 2 * j + 1; \
         a0[K] = add_tab<KIND, sv_out(p0, b)>(m[p0], t0, t1, t01);                 \
         a1[K] = add_tab<KIND, sv_out(p1, b)>(m[p1], t0, t1, t01);                 \
     }
@@ -1155,7 +1101,7 @@ __device__ __forceinline__ void acs_quad_c(const float (&m)[64], float (&o)[64],
 #pragma unroll
     for (int k = 0; k < 4; k++) df[k] = a0[k] - a1[k];
 #pragma unroll
-    for (int k = 0; k < 4; k++) o[N + k] = fmaxf(a0[k], a1[k]);
+    for (int k = 0; k < 4; k++) o[N + 8 * k] = fmaxf(a0[k], a1[k]);
 #pragma unroll
     for (int k = 0; k < 4; k++) dw[k] = __builtin_amdgcn_alignbit(dw[k], __float_as_uint(df[k]), 31);
 }
@@ -1164,83 +1110,66 @@ template <int KIND, int BASE, int... N>
 __device__ __forceinline__ void acs_range4(const float (&m)[64], float (&o)[64], float t0, float t1, float t01,
                                            uint32_t (&dw)[4], std::integer_sequence<int, N...>)
 {
-    (acs_quad_c<KIND, BASE + 4 * N>(m, o, t0, t1, t01, dw), ...);
+    (acs_quad<KIND, BASE + N>(m, o, t0, t1, t01, dw), ...);
 }
 
-template <int KIND, int BASE, int... N>
-__device__ __forceinline__ void acs_range(const float (&m)[64], float (&o)[64], float t0, float t1, float t01,
-                                          uint32_t &dw, std::integer_sequence<int, N...>)
-{
-#ifdef GR80211_ASM_ACS
-    (acs_quad<KIND, BASE + 4 * N>(m, o, t0, t1, t01, dw), ...);
-#else
-    (acs_one<KIND, BASE + N>(m, o, t0, t1, t01, dw), ...);
-#endif
-}
-
-// One trellis step for 64 frames.  Survivor bits of states 32w .. 32w+31 go to word w; within a word
-// state n sits at bit DEC_BIT(n) (see dec_bit()).
+// One trellis step for 64 frames.  Survivor bits of states 0..31 go to w0, of states 32..63 to w1;
+// within a word state n sits at bit dec_bit(n).
 template <int KIND>
-__device__ __forceinline__ void acs_step(const float (&m)[64], float (&o)[64], float t0, float t1, uint32_t *dec)
+__device__ __forceinline__ void acs_step(const float (&m)[64], float (&o)[64], float t0, float t1, uint32_t &w0,
+                                         uint32_t &w1)
 {
     const float t01 = t1 + t0;
-#if defined(GR80211_ASM_ACS) || defined(GR80211_PLAIN_ACS) || defined(GR80211_CHAIN_ACS)
-    uint32_t d0 = 0, d1 = 0;
-#ifdef GR80211_ASM_ACS
-    acs_range<KIND, 0>(m, o, t0, t1, t01, d0, std::make_integer_sequence<int, 8>{});
-    acs_range<KIND, 32>(m, o, t0, t1, t01, d1, std::make_integer_sequence<int, 8>{});
-#else
-    acs_range<KIND, 0>(m, o, t0, t1, t01, d0, std::make_integer_sequence<int, 32>{});
-    acs_range<KIND, 32>(m, o, t0, t1, t01, d1, std::make_integer_sequence<int, 32>{});
-#endif
-    dec[0] = d0;
-    dec[64] = d1;
-#else
     uint32_t qa[4] = {0, 0, 0, 0}, qb[4] = {0, 0, 0, 0};
     acs_range4<KIND, 0>(m, o, t0, t1, t01, qa, std::make_integer_sequence<int, 8>{});
     acs_range4<KIND, 32>(m, o, t0, t1, t01, qb, std::make_integer_sequence<int, 8>{});
-    // accumulator k holds states k, k+4, ..., k+28 (first in the top bit of its byte)
-    dec[0] = qa[0] | (qa[1] << 8) | (qa[2] << 16) | (qa[3] << 24);
-    dec[64] = qb[0] | (qb[1] << 8) | (qb[2] << 16) | (qb[3] << 24);
-#endif
+    // accumulator k holds states 8k .. 8k+7 of its half (first in the top bit of its byte)
+    w0 = qa[0] | (qa[1] << 8) | (qa[2] << 16) | (qa[3] << 24);
+    w1 = qb[0] | (qb[1] << 8) | (qb[2] << 16) | (qb[3] << 24);
 }
 
-// Bit position of state n's survivor bit inside its 32-bit decision word.
-__device__ __forceinline__ int dec_bit(int n)
-{
-#if defined(GR80211_ASM_ACS) || defined(GR80211_PLAIN_ACS) || defined(GR80211_CHAIN_ACS)
-    return 31 - (n & 31);
-#else
-    return 8 * (n & 3) + 7 - ((n & 31) >> 2);
-#endif
-}
+// Bit position of state n's survivor bit in the 64-bit word {w1:w0} of its step.
+__device__ __forceinline__ int dec_bit(int n) { return n ^ 7; }
 
+// Puncture patterns (lib/cloud80211phy.cc:1857-1860): P trellis steps consume COLS soft bits.
 template <int CR> struct Rate;
 template <> struct Rate<CR_12> { static constexpr int P = 1, COLS = 2, NPER = 32; };
 template <> struct Rate<CR_23> { static constexpr int P = 2, COLS = 3, NPER = 20; };
 template <> struct Rate<CR_34> { static constexpr int P = 3, COLS = 4, NPER = 16; };
 template <> struct Rate<CR_56> { static constexpr int P = 5, COLS = 6, NPER = 10; };
+// Step ps of a period: kind 0 = both soft bits present, 1 = second erased, 2 = first erased.
+constexpr int step_kind(int cr, int ps) { return (cr == CR_12 || ps == 0) ? 0 : (ps & 1) ? 1 : 2; }
+constexpr int step_col(int ps) { return ps == 0 ? 0 : ps + 1; }
 
-// One puncture period (lib/cloud80211phy.cc:1857-1860): starts in A; ends in B when P is odd.
-template <int CR>
-__device__ __forceinline__ void period(float (&A)[64], float (&B)[64], const float *c, uint32_t *dec)
+// Step S (0 .. 2P-1) of a pair of puncture periods whose soft bits start at c.  Even steps go from
+// A to B, odd steps back, so a pair of periods always starts and ends in A.
+template <int CR, int S>
+__device__ __forceinline__ void trellis_step(float (&A)[64], float (&B)[64], const float *c, uint32_t &w0, uint32_t &w1)
 {
-    if constexpr (CR == CR_12) {
-        acs_step<0>(A, B, c[0], c[1], dec);
-    } else if constexpr (CR == CR_23) {
-        acs_step<0>(A, B, c[0], c[1], dec);
-        acs_step<1>(B, A, c[2], 0.0f, dec + 128);
-    } else if constexpr (CR == CR_34) {
-        acs_step<0>(A, B, c[0], c[1], dec);
-        acs_step<1>(B, A, c[2], 0.0f, dec + 128);
-        acs_step<2>(A, B, 0.0f, c[3], dec + 256);
-    } else {
-        acs_step<0>(A, B, c[0], c[1], dec);
-        acs_step<1>(B, A, c[2], 0.0f, dec + 128);
-        acs_step<2>(A, B, 0.0f, c[3], dec + 256);
-        acs_step<1>(B, A, c[4], 0.0f, dec + 384);
-        acs_step<2>(A, B, 0.0f, c[5], dec + 512);
-    }
+    constexpr int P = Rate<CR>::P, ps = S % P, kind = step_kind(CR, ps);
+    constexpr int col = (S / P) * Rate<CR>::COLS + step_col(ps);
+    const float t0 = kind == 2 ? 0.0f : c[col];
+    const float t1 = kind == 0 ? c[col + 1] : kind == 2 ? c[col] : 0.0f;
+    if constexpr (S & 1) acs_step<kind>(B, A, t0, t1, w0, w1);
+    else acs_step<kind>(A, B, t0, t1, w0, w1);
+}
+
+// Steps 2U and 2U+1; their four survivor words leave as one 16-byte store per lane
+// (survivor layout: [step pair][lane][w0(even) w1(even) w0(odd) w1(odd)]).
+template <int CR, int U>
+__device__ __forceinline__ void step_pair(float (&A)[64], float (&B)[64], const float *c, uint32_t *dp)
+{
+    uint4 v;
+    trellis_step<CR, 2 * U>(A, B, c, v.x, v.y);
+    trellis_step<CR, 2 * U + 1>(A, B, c, v.z, v.w);
+    *reinterpret_cast<uint4 *>(dp + U * 256) = v;
+}
+
+template <int CR, int... U>
+__device__ __forceinline__ void two_periods(float (&A)[64], float (&B)[64], const float *c, uint32_t *dp,
+                                            std::integer_sequence<int, U...>)
+{
+    (step_pair<CR, U>(A, B, c, dp), ...);
 }
 
 constexpr int TILE_STRIDE = 65;
@@ -1277,13 +1206,10 @@ __device__ __forceinline__ void viterbi_group(const float *__restrict__ llr, uns
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        uint32_t *dp = dec + (size_t)ch * STEPS * 128 + lane;
+        uint32_t *dp = dec + (size_t)ch * STEPS * 128 + lane * 4;
 #pragma unroll 1
-        for (int pp = 0; pp < NPER; pp += 2) {
-            period<CR>(A, B, row + pp * COLS, dp + (size_t)pp * P * 128);
-            if constexpr (P & 1) period<CR>(B, A, row + (pp + 1) * COLS, dp + (size_t)(pp + 1) * P * 128);
-            else period<CR>(A, B, row + (pp + 1) * COLS, dp + (size_t)(pp + 1) * P * 128);
-        }
+        for (int pp = 0; pp < NPER; pp += 2)
+            two_periods<CR>(A, B, row + pp * COLS, dp + (size_t)pp * P * 128, std::make_integer_sequence<int, P>{});
     }
 }
 
@@ -1326,64 +1252,84 @@ __device__ __forceinline__ void traceback_group(const uint32_t *__restrict__ dec
                                                 uint8_t *__restrict__ bits_out, int bits_stride)
 {
     const int T = fr >= 0 ? info[fr].trellis : 0;
-    const uint32_t *d = dec + gi.dec_off + lane;
     uint32_t *bw = bitsw + gi.bits_off + lane;
 
     // ---- traceback from state 0 at step T (lib/decode_impl.cc:282-302).  The survivor words do not
-    // depend on the path, so they are fetched into a ring of four register sets: three blocks of
-    // 2*TB coalesced 256-B loads stay in flight while the dependent bit-extract chain walks one.
+    // depend on the path, so they are fetched into a ring of four register sets (16 steps each):
+    // three sets of 1-KiB coalesced loads stay in flight while the dependent chain walks the fourth.
+    // The walk keeps the path in a shift register S: the state after step t is S & 63, its newest bit
+    // (bit 5) is decoded bit t, and one step back is S = (S << 1) | survivor bit.  Decoded bits thus
+    // line up in S in time order and leave 16 at a time; per step the chain is xor, 64-bit shift,
+    // and-or.  Steps at or above a lane's own trellis length produce bits nobody reads; S is reset
+    // when the lane's last step is reached, which can only happen in the topmost blocks.
     {
         constexpr int TB = 16;
-        int s = 0;
-        uint32_t acc = 0;
-        uint32_t wa[2 * TB], wb[2 * TB], wc[2 * TB], wd[2 * TB];
-        const int steps = gi.steps;
-        const int nblk = (steps + TB - 1) / TB;
-#define GR_TB_FETCH(W, BLK)                                  \
+        uint32_t S = 0;
+        uint4 wa[TB / 2], wb[TB / 2], wc[TB / 2], wd[TB / 2];
+        const int steps = gi.steps;          // even: whole pairs of puncture periods
+        const int nb32 = (steps + 31) >> 5;  // 32-step blocks = decoded words per lane
+        const int umax = (steps - 1) >> 1;
+        int tmin = fr >= 0 ? T : 0x7fffffff;
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) {
+            const int o = __shfl_xor(tmin, m);
+            tmin = o < tmin ? o : tmin;
+        }
+        tmin = __builtin_amdgcn_readfirstlane(tmin);
+        const uint4 *d4 = reinterpret_cast<const uint4 *>(dec + gi.dec_off) + lane;
+        // half-block h (from the top): steps 16*(2*nb32-1-h)+15 .. 16*(2*nb32-1-h)
+#define GR_TB_FETCH(W, H)                                    \
     {                                                        \
-        const int thi = steps - 1 - (BLK) * TB;              \
-        _Pragma("unroll") for (int k = 0; k < TB; k++) {     \
-            int t = thi - k;                                 \
-            t = t < 0 ? 0 : t;                               \
-            W[2 * k] = d[(size_t)t * 128];                   \
-            W[2 * k + 1] = d[(size_t)t * 128 + 64];          \
+        const int uhi = (16 * (2 * nb32 - 1 - (H)) + 15) >> 1; \
+        _Pragma("unroll") for (int k = 0; k < TB / 2; k++) { \
+            int u = uhi - k;                                 \
+            u = u > umax ? umax : u;                         \
+            u = u < 0 ? 0 : u;                               \
+            W[k] = d4[(size_t)u * 64];                       \
         }                                                    \
     }
-#define GR_TB_WALK(W, BLK)                                                                          \
+#define GR_TB_WALK(W, THI, CHECK)                                                                   \
     {                                                                                               \
-        const int thi = steps - 1 - (BLK) * TB;                                                     \
         _Pragma("unroll") for (int k = 0; k < TB; k++) {                                            \
-            const int t = thi - k;                                                                  \
-            if (t >= 0) {                                                                           \
-                if (t == T - 1) s = 0;                                                              \
-                acc |= (uint32_t)(s >> 5) << (t & 31); /* bit t = newest bit of the state after step t */ \
-                /* both words are shifted first: selecting between the two array elements would be   \
-                   turned into a run-time array index and push the register sets into scratch */    \
-                const int pos = dec_bit(s);                                                         \
-                const uint32_t b0 = W[2 * k] >> pos, b1 = W[2 * k + 1] >> pos;                      \
-                const int dbit = (int)(((s & 32) ? b1 : b0) & 1u);                                  \
-                s = ((s & 31) << 1) | dbit;                                                         \
-                if ((t & 31) == 0) {                                                                \
-                    bw[(size_t)(t >> 5) * 64] = acc;                                                \
-                    acc = 0;                                                                        \
-                }                                                                                   \
-            }                                                                                       \
+            if (CHECK) S = ((THI) - k == T - 1) ? 0u : S;                                           \
+            const uint32_t w0 = (k & 1) ? W[k >> 1].x : W[k >> 1].z;                                \
+            const uint32_t w1 = (k & 1) ? W[k >> 1].y : W[k >> 1].w;                                \
+            const unsigned long long w = ((unsigned long long)w1 << 32) | w0;                       \
+            const uint32_t sh = (uint32_t)(w >> ((S ^ 7u) & 63u));                                  \
+            S = (S << 1) | (sh & 1u);                                                               \
         }                                                                                           \
+    }
+        // one 32-step block = two half-blocks; S >> 6 after a half holds its 16 decoded bits
+#define GR_TB_BLOCK(WH, WL, B32, HNEXT)                                                             \
+    if ((B32) >= 0) {                                                                               \
+        const int thi = 32 * (B32) + 31;                                                            \
+        uint32_t hi16, lo16;                                                                        \
+        if (thi >= tmin - 1) {                                                                      \
+            GR_TB_WALK(WH, thi, true)                                                               \
+            hi16 = (S >> 6) & 0xffffu;                                                              \
+            GR_TB_FETCH(WH, HNEXT)                                                                  \
+            GR_TB_WALK(WL, thi - 16, true)                                                          \
+            lo16 = (S >> 6) & 0xffffu;                                                              \
+            GR_TB_FETCH(WL, (HNEXT) + 1)                                                            \
+        } else {                                                                                    \
+            GR_TB_WALK(WH, thi, false)                                                              \
+            hi16 = (S >> 6) & 0xffffu;                                                              \
+            GR_TB_FETCH(WH, HNEXT)                                                                  \
+            GR_TB_WALK(WL, thi - 16, false)                                                         \
+            lo16 = (S >> 6) & 0xffffu;                                                              \
+            GR_TB_FETCH(WL, (HNEXT) + 1)                                                            \
+        }                                                                                           \
+        bw[(size_t)(B32) * 64] = lo16 | (hi16 << 16);                                               \
     }
         GR_TB_FETCH(wa, 0)
         GR_TB_FETCH(wb, 1)
         GR_TB_FETCH(wc, 2)
         GR_TB_FETCH(wd, 3)
-        for (int blk = 0; blk < nblk; blk += 4) {
-            GR_TB_WALK(wa, blk)
-            GR_TB_FETCH(wa, blk + 4)
-            GR_TB_WALK(wb, blk + 1)
-            GR_TB_FETCH(wb, blk + 5)
-            GR_TB_WALK(wc, blk + 2)
-            GR_TB_FETCH(wc, blk + 6)
-            GR_TB_WALK(wd, blk + 3)
-            GR_TB_FETCH(wd, blk + 7)
+        for (int b32 = nb32 - 1, h = 4; b32 >= 0; b32 -= 2, h += 4) {
+            GR_TB_BLOCK(wa, wb, b32, h)
+            GR_TB_BLOCK(wc, wd, b32 - 1, h + 2)
         }
+#undef GR_TB_BLOCK
 #undef GR_TB_FETCH
 #undef GR_TB_WALK
     }
