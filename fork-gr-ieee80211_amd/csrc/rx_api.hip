@@ -299,6 +299,23 @@ int gr80211_rx_batch(gr80211_ctx *c, const void *d_iq0, const void *d_iq1, uint6
     return finish_timing(c, s);
 }
 
+int gr80211_signal_batch(gr80211_ctx *c, const void *d_iq0, const void *d_iq1, uint64_t arena_len,
+                         const gr80211_frame_desc *desc, int n, unsigned flags, gr80211_frame_info *d_info, void *stream)
+{
+    if (!c) return GR80211_ERR_ARG;
+    if (n == 0) return GR80211_OK;
+    if (!d_iq0 || !desc || n < 0 || !d_info) return fail(c, GR80211_ERR_ARG, "gr80211_signal_batch: bad argument");
+    if (n > (1 << 20)) return fail(c, GR80211_ERR_ARG, "gr80211_signal_batch: at most 1048576 frames per call");
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = pick(c, stream);
+    const gr80211_frame_desc *dd = nullptr;
+    int rc = front_end(c, s, d_iq0, d_iq1, arena_len, desc, n, flags, &dd);
+    if (rc) return rc;
+    HIP_TRY(c, hipMemcpyAsync(d_info, c->info.p, (size_t)n * sizeof(gr80211_frame_info), hipMemcpyDeviceToDevice, s));
+    HIP_TRY(c, hipGetLastError());
+    return GR80211_OK;
+}
+
 int gr80211_demod_batch(gr80211_ctx *c, const void *d_iq0, const void *d_iq1, uint64_t arena_len,
                         const gr80211_frame_desc *desc, int n, unsigned flags, gr80211_frame_info *d_info,
                         const float **d_llr, uint64_t *llr_floats, void *stream)

@@ -1,0 +1,469 @@
+// Host blocks over the C-ABI of libgr80211_rx.so (see gr80211_blocks.h).
+#include "gr80211_blocks.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+
+namespace gr80211 {
+namespace host {
+
+namespace {
+
+const int LSIG_SPAN = 224;       // samples from the trigger to the end of L-SIG (lib/signal_impl.cc:110,154)
+const int LSIG_FAIL_SKIP = 80;   // samples dropped after a failed L-SIG check (lib/signal_impl.cc:156-160)
+const int OUT_STRIDE = 4352;     // room for the PDUs of one frame: 4095 bytes + headers of a few subframes
+const long DEFAULT_TAG = 99999;  // value `decode` assumes for a missing tag (lib/decode_impl.cc:77-83)
+
+double tag_value(const std::vector<tag_t> &tags, const char *key, double dflt)
+{
+    // pmt::dict_add overwrites, so the last tag of a key wins (lib/decode_impl.cc:73-76)
+    double v = dflt;
+    for (const tag_t &t : tags)
+        if (t.key == key) v = t.value;
+    return v;
+}
+
+const tag_t *tag_find(const std::vector<tag_t> &tags, const char *key)
+{
+    const tag_t *r = nullptr;
+    for (const tag_t &t : tags)
+        if (t.key == key) r = &t;
+    return r;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------ block
+block::block(int n_in) : d_read(n_in, 0), d_tags(n_in) {}
+block::~block() {}
+
+void block::add_item_tag_in(int port, const tag_t &t) { d_tags[port].push_back(t); }
+
+void block::get_tags_in_range(std::vector<tag_t> &v, int port, uint64_t start, uint64_t end) const
+{
+    v.clear();
+    for (const tag_t &t : d_tags[port])
+        if (t.offset >= start && t.offset < end) v.push_back(t);
+}
+
+void block::commit()
+{
+    for (size_t p = 0; p < d_read.size(); p++) {
+        d_read[p] += (uint64_t)d_consumed;
+        std::vector<tag_t> &tv = d_tags[p];
+        size_t k = 0;
+        while (k < tv.size() && tv[k].offset < d_read[p]) k++;
+        if (k) tv.erase(tv.begin(), tv.begin() + k);
+    }
+    d_consumed = 0;
+}
+
+void block::message_port_pub(const std::string &port, const pdu_t &m)
+{
+    if (d_handler) d_handler(port, m);
+}
+
+// ------------------------------------------------------------------------------------ gpu_session
+gpu_session::gpu_session(int device)
+{
+    if (gr80211_create(&d_ctx, device) != GR80211_OK) d_ctx = nullptr;
+}
+
+gpu_session::~gpu_session()
+{
+    if (!d_ctx) return;
+    for (dbuf &b : d_buf)
+        if (b.p) gr80211_dev_free(d_ctx, b.p);
+    gr80211_destroy(d_ctx);
+}
+
+void *gpu_session::buffer(int slot, size_t bytes)
+{
+    dbuf &b = d_buf[slot];
+    if (bytes <= b.cap) return b.p;
+    if (b.p) gr80211_dev_free(d_ctx, b.p);
+    b.cap = bytes + bytes / 4 + 4096;
+    b.p = gr80211_dev_alloc(d_ctx, b.cap);
+    if (!b.p) b.cap = 0;
+    return b.p;
+}
+
+std::string gpu_session::error() const { return d_ctx ? gr80211_last_error(d_ctx) : "no GPU context"; }
+
+// ------------------------------------------------------------------------------------ decode
+decode::sptr decode::make(bool ifdebug, int batch_frames, int device)
+{
+    return sptr(new decode(ifdebug, batch_frames, device));
+}
+
+decode::decode(bool ifdebug, int batch_frames, int device)
+    : block(1), d_debug(ifdebug), d_batch(batch_frames < 1 ? 1 : batch_frames), d_gpu(device)
+{
+    if (!d_gpu.ok()) d_err = "gr80211_create failed";
+}
+
+decode::~decode() {}
+
+void decode::forecast(int noutput_items, gr_vector_int &ninput_items_required)
+{
+    ninput_items_required[0] = noutput_items + 160;  // lib/decode_impl.cc:54-58
+}
+
+int decode::general_work(int, gr_vector_int &ninput_items, gr_vector_const_void_star &input_items, gr_vector_void_star &)
+{
+    const float *in = static_cast<const float *>(input_items[0]);
+    const int n = ninput_items[0];
+    int used = 0;
+    std::vector<tag_t> tags;
+    while (used < n) {
+        if (d_state == S_IDLE) {
+            const uint64_t at = nitems_read(0) + (uint64_t)used;
+            get_tags_in_range(tags, 0, at, at + 1);
+            if (tags.empty()) {
+                // The reference stays idle until an item carries tags (lib/decode_impl.cc:70-72,125-126);
+                // untagged items between packets are passed over here.
+                get_tags_in_range(tags, 0, at + 1, nitems_read(0) + (uint64_t)n);
+                if (tags.empty()) {
+                    used = n;
+                    break;
+                }
+                used = (int)(tags[0].offset - nitems_read(0));
+                continue;
+            }
+            t_format = (long)tag_value(tags, "format", DEFAULT_TAG);
+            t_len = (long)tag_value(tags, "len", DEFAULT_TAG);
+            t_nTotal = (long)tag_value(tags, "total", DEFAULT_TAG);
+            t_cr = (long)tag_value(tags, "cr", DEFAULT_TAG);
+            t_mcs = (long)tag_value(tags, "mcs", DEFAULT_TAG);
+            t_ampdu = (long)tag_value(tags, "ampdu", DEFAULT_TAG);
+            v_trellis = (long)tag_value(tags, "trellis", DEFAULT_TAG);
+            t_nProcd = 0;
+            d_nSeen++;
+            if (t_nTotal <= 0) {  // a packet without items cannot be passed over by counting items
+                used++;
+                continue;
+            }
+            if (t_len > GR80211_MAX_PSDU || v_trellis > GR80211_MAX_TRELLIS) {
+                d_state = S_CLEAN;  // lib/decode_impl.cc:93-97
+            } else if (v_trellis == 0) {
+                // VHT NDP: the 2x1 channel dump travels as a message of its own (lib/decode_impl.cc:100-121)
+                d_state = S_CLEAN;
+                const tag_t *ch = tag_find(tags, "mu2x1chan");
+                pdu_t m;
+                const int nbytes = (int)sizeof(float) * 256;
+                m.blob.assign(nbytes + 3, 0);
+                m.blob[0] = 20;  // C8P_F_VHT_CHAN
+                m.blob[1] = (uint8_t)(nbytes % 256);
+                m.blob[2] = (uint8_t)(nbytes / 256);
+                if (ch) {
+                    float *f = reinterpret_cast<float *>(&m.blob[3]);
+                    for (size_t i = 0; i < 128 && i < ch->cvec.size(); i++) {
+                        const float re = ch->cvec[i].real(), im = ch->cvec[i].imag();
+                        memcpy(f + 2 * i, &re, 4);
+                        memcpy(f + 2 * i + 1, &im, 4);
+                    }
+                }
+                m.len = nbytes + 3;
+                message_port_pub("out", m);
+                d_nPdu++;
+            } else {
+                d_state = S_COLLECT;
+            }
+            if (d_state == S_COLLECT) {
+                gr80211_dec_desc d;
+                memset(&d, 0, sizeof(d));
+                d.llr_off = (int64_t)d_llr.size();
+                d.n_llr = (int32_t)t_nTotal;
+                d.format = (int32_t)t_format;
+                d.len = (int32_t)t_len;
+                d.cr = (int32_t)t_cr;
+                d.mcs = (int32_t)t_mcs;
+                d.ampdu = (int32_t)t_ampdu;
+                d.trellis = (int32_t)v_trellis;
+                d_desc.push_back(d);
+            }
+        }
+        if (d_state == S_COLLECT || d_state == S_CLEAN) {
+            const long need = t_nTotal - t_nProcd;
+            const int take = (int)std::min<long>(need < 0 ? 0 : need, n - used);
+            if (d_state == S_COLLECT) d_llr.insert(d_llr.end(), in + used, in + used + take);
+            t_nProcd += take;
+            used += take;
+            if (t_nProcd >= t_nTotal) {
+                const bool collected = d_state == S_COLLECT;
+                d_state = S_IDLE;
+                if (collected && (int)d_desc.size() >= d_batch && !run_batch()) {
+                    consume_each(used);
+                    return 0;
+                }
+            }
+        }
+    }
+    consume_each(used);
+    return 0;
+}
+
+bool decode::flush()
+{
+    // a packet cut off by the end of the stream is dropped, as the reference never finishes it either
+    if (d_state == S_COLLECT && !d_desc.empty()) {
+        d_llr.resize((size_t)d_desc.back().llr_off);
+        d_desc.pop_back();
+    }
+    d_state = S_IDLE;
+    return run_batch();
+}
+
+bool decode::run_batch()
+{
+    // called between packets only: every pending descriptor has all of its soft bits
+    const int n = (int)d_desc.size();
+    if (n <= 0) return true;
+    if (!d_gpu.ok()) return false;
+    const size_t nfl = d_llr.size();
+    void *dl = d_gpu.buffer(0, (nfl + 64) * sizeof(float));
+    uint8_t *dout = static_cast<uint8_t *>(d_gpu.buffer(1, (size_t)n * OUT_STRIDE));
+    int32_t *dlen = static_cast<int32_t *>(d_gpu.buffer(2, (size_t)n * 4));
+    int32_t *dnp = static_cast<int32_t *>(d_gpu.buffer(3, (size_t)n * 4));
+    if (!dl || !dout || !dlen || !dnp) {
+        d_err = "device allocation failed";
+        return false;
+    }
+    gr80211_ctx *c = d_gpu.ctx();
+    std::vector<uint8_t> out((size_t)n * OUT_STRIDE);
+    std::vector<int32_t> len(n);
+    if (gr80211_copy_h2d(c, dl, d_llr.data(), nfl * sizeof(float), nullptr) != GR80211_OK ||
+        gr80211_decode_batch(c, static_cast<const float *>(dl), nfl, d_desc.data(), n, 0, dout, OUT_STRIDE, dlen, dnp,
+                             nullptr, 0, nullptr) != GR80211_OK ||
+        gr80211_copy_d2h(c, len.data(), dlen, (size_t)n * 4, nullptr) != GR80211_OK ||
+        gr80211_copy_d2h(c, out.data(), dout, out.size(), nullptr) != GR80211_OK) {
+        d_err = d_gpu.error();
+        return false;
+    }
+    for (int i = 0; i < n; i++) {
+        // a slot holds the frame's messages back to back: [format][len lo][len hi][MPDU][mcs]
+        const uint8_t *p = &out[(size_t)i * OUT_STRIDE];
+        int at = 0;
+        while (at + 4 <= len[i]) {
+            const int L = p[at + 1] | (p[at + 2] << 8);
+            pdu_t m;
+            m.blob.assign(p + at, p + at + L + 4);
+            m.len = L + 4;
+            message_port_pub("out", m);
+            d_nPdu++;
+            at += L + 4;
+        }
+    }
+    d_llr.clear();
+    d_desc.clear();
+    return true;
+}
+
+// ------------------------------------------------------------------------------------ rx
+rx::sptr rx::make(int n_rx, int batch_frames, int device) { return sptr(new rx(n_rx, batch_frames, device)); }
+
+rx::rx(int n_rx, int batch_frames, int device)
+    : block(n_rx == 2 ? 3 : 2), d_nrx(n_rx == 2 ? 2 : 1), d_batch(batch_frames < 1 ? 1 : batch_frames), d_gpu(device),
+      d_maxHold((size_t)1 << 22)
+{
+    if (!d_gpu.ok()) d_err = "gr80211_create failed";
+}
+
+rx::~rx() {}
+
+void rx::forecast(int noutput_items, gr_vector_int &ninput_items_required)
+{
+    for (int &v : ninput_items_required) v = noutput_items;  // lib/signal_impl.cc:55-60
+}
+
+int rx::general_work(int, gr_vector_int &ninput_items, gr_vector_const_void_star &input_items, gr_vector_void_star &)
+{
+    const uint8_t *sync = static_cast<const uint8_t *>(input_items[0]);
+    int n = std::min(ninput_items[0], ninput_items[1]);
+    if (d_nrx == 2) n = std::min(n, ninput_items[2]);
+    std::vector<tag_t> tags;
+    for (int i = 0; i < n; i++) {
+        if (!sync[i]) continue;
+        const uint64_t at = nitems_read(0) + (uint64_t)i;
+        get_tags_in_range(tags, 0, at, at + 1);
+        if (tags.empty()) continue;  // "input sync with no tag" (lib/signal_impl.cc:96-100): not a trigger
+        trigger t;
+        t.pos = at;
+        t.rad = (float)tag_value(tags, "rad", 0.0);
+        t.snr = (float)tag_value(tags, "snr", 0.0);
+        t.rssi = (float)tag_value(tags, "rssi", 0.0);
+        t.probed = false;
+        t.status = 0;
+        t.nsamp = 0;
+        d_trig.push_back(t);
+        d_nTrig++;
+    }
+    // samples are only held from the first pending trigger on
+    int from = 0;
+    if (d_hold[0].empty()) {
+        if (d_trig.empty()) {
+            from = n;
+        } else {
+            const uint64_t first = std::max(d_trig[0].pos, nitems_read(0));
+            from = (int)(first - nitems_read(0));
+        }
+        d_base = nitems_read(0) + (uint64_t)from;
+    }
+    for (int a = 0; a < d_nrx; a++) {
+        const gr_complex *s = static_cast<const gr_complex *>(input_items[1 + a]);
+        d_hold[a].insert(d_hold[a].end(), s + from, s + n);
+    }
+    consume_each(n);
+    if ((int)d_trig.size() >= d_batch || d_hold[0].size() >= d_maxHold) process(false);
+    return 0;
+}
+
+bool rx::flush() { return process(true); }
+
+// One round: learn the span of every buffered trigger (L-SIG), replay the trigger/copy state machine of
+// `signal` over them in stream order, decode the frames whose samples are complete, release what is done.
+bool rx::process(bool final)
+{
+    const uint64_t held_end = d_base + d_hold[0].size();
+    // triggers at or behind the search position can never start a frame
+    {
+        size_t k = 0;
+        while (k < d_trig.size() && d_trig[k].pos < d_cursor) k++;
+        if (k) d_trig.erase(d_trig.begin(), d_trig.begin() + (long)k);
+    }
+    if (d_trig.empty()) {
+        // nothing pending: everything held so far can go
+        d_cursor = std::max(d_cursor, held_end);
+        for (int a = 0; a < d_nrx; a++) d_hold[a].clear();
+        d_base = held_end;
+        return true;
+    }
+    if (!d_gpu.ok()) return false;
+    gr80211_ctx *c = d_gpu.ctx();
+    const size_t nheld = d_hold[0].size();
+    void *diq0 = d_gpu.buffer(0, (nheld + 64) * sizeof(gr_complex));
+    void *diq1 = d_nrx == 2 ? d_gpu.buffer(1, (nheld + 64) * sizeof(gr_complex)) : nullptr;
+    if (!diq0 || (d_nrx == 2 && !diq1)) {
+        d_err = "device allocation failed";
+        return false;
+    }
+    if (gr80211_copy_h2d(c, diq0, d_hold[0].data(), nheld * sizeof(gr_complex), nullptr) != GR80211_OK ||
+        (d_nrx == 2 && gr80211_copy_h2d(c, diq1, d_hold[1].data(), nheld * sizeof(gr_complex), nullptr) != GR80211_OK)) {
+        d_err = d_gpu.error();
+        return false;
+    }
+
+    // ---- 1. spans: L-SIG of every trigger that has its 224 samples (lib/signal_impl.cc:108-131)
+    std::vector<gr80211_frame_desc> pd;
+    std::vector<size_t> pidx;
+    for (size_t j = 0; j < d_trig.size(); j++) {
+        trigger &t = d_trig[j];
+        if (t.probed) continue;
+        const uint64_t rel = t.pos - d_base;
+        if (rel + LSIG_SPAN > nheld) continue;  // `signal` waits for 224 samples too
+        gr80211_frame_desc d;
+        memset(&d, 0, sizeof(d));
+        d.sync_off = rel;
+        d.n_avail = (uint32_t)std::min<uint64_t>(nheld - rel, 0xffffffffu);
+        d.rad = t.rad;
+        d.snr = t.snr;
+        d.rssi = t.rssi;
+        pd.push_back(d);
+        pidx.push_back(j);
+    }
+    if (!pd.empty()) {
+        const int np = (int)pd.size();
+        gr80211_frame_info *dinfo =
+            static_cast<gr80211_frame_info *>(d_gpu.buffer(2, (size_t)np * sizeof(gr80211_frame_info)));
+        std::vector<gr80211_frame_info> info(np);
+        if (!dinfo || gr80211_signal_batch(c, diq0, diq1, nheld, pd.data(), np, 0, dinfo, nullptr) != GR80211_OK ||
+            gr80211_copy_d2h(c, info.data(), dinfo, (size_t)np * sizeof(gr80211_frame_info), nullptr) != GR80211_OK) {
+            d_err = d_gpu.error();
+            return false;
+        }
+        for (int k = 0; k < np; k++) {
+            trigger &t = d_trig[pidx[k]];
+            t.probed = true;
+            t.status = info[k].status;
+            t.nsamp = info[k].nsamp;
+        }
+    }
+
+    // ---- 2. the trigger search in stream order (lib/signal_impl.cc:75-106,153-160,164-202)
+    std::vector<gr80211_frame_desc> fd;
+    size_t done = 0;  // triggers settled in this round
+    for (size_t j = 0; j < d_trig.size(); j++) {
+        const trigger &t = d_trig[j];
+        if (t.pos < d_cursor) {  // inside the previous frame's span: `signal` never looks at it
+            done = j + 1;
+            continue;
+        }
+        if (!t.probed) {
+            if (final) done = j + 1;  // fewer than 224 samples before the end of the stream
+            break;
+        }
+        if (t.status == GR80211_ST_DROP_LSIG) {
+            d_cursor = t.pos + LSIG_FAIL_SKIP;
+            done = j + 1;
+            continue;
+        }
+        const uint64_t span = (uint64_t)LSIG_SPAN + (uint64_t)(t.nsamp > 0 ? t.nsamp : 0);
+        if (t.pos + span > held_end && !final) break;  // its samples are still arriving
+        gr80211_frame_desc d;
+        memset(&d, 0, sizeof(d));
+        d.sync_off = t.pos - d_base;
+        d.n_avail = (uint32_t)std::min<uint64_t>(span, held_end - t.pos);
+        d.rad = t.rad;
+        d.snr = t.snr;
+        d.rssi = t.rssi;
+        fd.push_back(d);
+        d_cursor = t.pos + span;
+        done = j + 1;
+    }
+
+    // ---- 3. decode the complete frames and publish their PDUs in stream order
+    if (!fd.empty()) {
+        const int nf = (int)fd.size();
+        uint8_t *dout = static_cast<uint8_t *>(d_gpu.buffer(3, (size_t)nf * OUT_STRIDE));
+        int32_t *dlen = static_cast<int32_t *>(d_gpu.buffer(4, (size_t)nf * 4));
+        int32_t *dnp = static_cast<int32_t *>(d_gpu.buffer(5, (size_t)nf * 4));
+        std::vector<uint8_t> out((size_t)nf * OUT_STRIDE);
+        std::vector<int32_t> len(nf);
+        if (!dout || !dlen || !dnp ||
+            gr80211_rx_batch(c, diq0, diq1, nheld, fd.data(), nf, 0, dout, OUT_STRIDE, dlen, dnp, nullptr, nullptr) !=
+                GR80211_OK ||
+            gr80211_copy_d2h(c, len.data(), dlen, (size_t)nf * 4, nullptr) != GR80211_OK ||
+            gr80211_copy_d2h(c, out.data(), dout, out.size(), nullptr) != GR80211_OK) {
+            d_err = d_gpu.error();
+            return false;
+        }
+        d_nFrames += (uint64_t)nf;
+        for (int i = 0; i < nf; i++) {
+            const uint8_t *p = &out[(size_t)i * OUT_STRIDE];
+            int at = 0;
+            while (at + 4 <= len[i]) {
+                const int L = p[at + 1] | (p[at + 2] << 8);
+                pdu_t m;
+                m.blob.assign(p + at, p + at + L + 4);
+                m.len = L + 4;
+                message_port_pub("out", m);
+                d_nPdu++;
+                at += L + 4;
+            }
+        }
+    }
+
+    // ---- 4. release settled triggers and the samples nothing pending can need
+    d_trig.erase(d_trig.begin(), d_trig.begin() + (long)done);
+    uint64_t keep_from = held_end;
+    if (!d_trig.empty() && !final) keep_from = std::min(keep_from, std::max(d_trig[0].pos, d_base));
+    if (final) d_trig.clear();
+    const size_t drop = (size_t)(keep_from - d_base);
+    for (int a = 0; a < d_nrx; a++) d_hold[a].erase(d_hold[a].begin(), d_hold[a].begin() + (long)drop);
+    d_base = keep_from;
+    return true;
+}
+
+}  // namespace host
+}  // namespace gr80211

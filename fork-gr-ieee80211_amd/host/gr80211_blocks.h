@@ -1,0 +1,173 @@
+// Host side of the MI355X RX path: C++ blocks with the work()/forecast()/tag/message interface of the
+// reference's GNU Radio blocks, calling the C-ABI of libgr80211_rx.so underneath.
+//
+//   gr80211::host::decode  -- drop-in for ieee80211::decode  (include/gnuradio/ieee80211/decode.h:22-36,
+//                             lib/decode_impl.cc:33-162): float soft-bit stream + tags in, PDU messages out.
+//   gr80211::host::rx      -- signal(2) -> demod(2) -> decode fused into one block with the input contract of
+//                             ieee80211::signal/signal2 (lib/signal_impl.cc:34-106, lib/signal2_impl.cc:34-110:
+//                             sync byte stream with tags rad/snr/rssi + one or two complex sample streams) and
+//                             the output contract of ieee80211::decode (message port "out").
+//
+// GNU Radio itself is not a dependency: `block` below carries the few scheduler services those blocks use
+// (nitems_read, get_tags_in_range, consume_each, message_port_pub), so a gr::block wrapper only forwards.
+// Blocks collect whole frames and hand them to the GPU in batches; a batch is cut when `batch_frames` frames
+// are pending, when flush() is called, or when the sample hold reaches its limit.
+#pragma once
+
+#include <complex>
+#include <cstdint>
+#include <functional>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/gr80211_rx.h"
+
+namespace gr80211 {
+namespace host {
+
+typedef std::complex<float> gr_complex;
+typedef std::vector<int> gr_vector_int;
+typedef std::vector<const void *> gr_vector_const_void_star;
+typedef std::vector<void *> gr_vector_void_star;
+
+// Stream tag with the value kinds of the RX chain's tags (pmt long / float / c32vector).
+struct tag_t {
+    uint64_t offset = 0;
+    std::string key;
+    double value = 0.0;
+    std::vector<gr_complex> cvec;
+};
+
+// Message of port "out": pmt::cons(dict{"len": len}, blob)  (lib/decode_impl.cc:512-516).
+struct pdu_t {
+    long len = 0;
+    std::vector<uint8_t> blob;
+};
+
+class block
+{
+public:
+    virtual ~block();
+    virtual void forecast(int noutput_items, gr_vector_int &ninput_items_required) = 0;
+    virtual int general_work(int noutput_items, gr_vector_int &ninput_items, gr_vector_const_void_star &input_items,
+                             gr_vector_void_star &output_items) = 0;
+    // End of stream: decode whatever is buffered.  Returns false on a GPU / API error (see last_error()).
+    virtual bool flush() { return true; }
+
+    // ---- scheduler side
+    void add_item_tag_in(int port, const tag_t &t);  // tags must arrive in non-decreasing offset order per port
+    void set_msg_handler(std::function<void(const std::string &port, const pdu_t &msg)> f) { d_handler = std::move(f); }
+    uint64_t nitems_read(int port) const { return d_read[port]; }
+    int consumed() const { return d_consumed; }  // items consumed by the last general_work call (every port)
+    void commit();                               // advance nitems_read by consumed(), forget passed tags
+    const std::string &last_error() const { return d_err; }
+
+protected:
+    explicit block(int n_in);
+    void consume_each(int n) { d_consumed = n; }
+    void get_tags_in_range(std::vector<tag_t> &v, int port, uint64_t start, uint64_t end) const;
+    void message_port_pub(const std::string &port, const pdu_t &m);
+    std::string d_err;
+
+private:
+    std::vector<uint64_t> d_read;
+    std::vector<std::vector<tag_t>> d_tags;
+    int d_consumed = 0;
+    std::function<void(const std::string &, const pdu_t &)> d_handler;
+};
+
+// Owns a gr80211 context and a few growable device buffers.
+class gpu_session
+{
+public:
+    explicit gpu_session(int device);
+    ~gpu_session();
+    gpu_session(const gpu_session &) = delete;
+    gpu_session &operator=(const gpu_session &) = delete;
+    bool ok() const { return d_ctx != nullptr; }
+    gr80211_ctx *ctx() const { return d_ctx; }
+    void *buffer(int slot, size_t bytes);  // device buffer `slot` of at least `bytes` (contents not preserved)
+    std::string error() const;
+
+private:
+    gr80211_ctx *d_ctx = nullptr;
+    struct dbuf {
+        void *p = nullptr;
+        size_t cap = 0;
+    };
+    dbuf d_buf[8];
+};
+
+class decode : public block
+{
+public:
+    typedef std::shared_ptr<decode> sptr;
+    // ifdebug as in ieee80211::decode::make(bool) (the reference only prints with it); batch_frames and
+    // device are the GPU side's knobs and default to values that keep a stream decoder busy.
+    static sptr make(bool ifdebug = false, int batch_frames = 4096, int device = 0);
+    ~decode() override;
+
+    void forecast(int noutput_items, gr_vector_int &ninput_items_required) override;
+    int general_work(int noutput_items, gr_vector_int &ninput_items, gr_vector_const_void_star &input_items,
+                     gr_vector_void_star &output_items) override;
+    bool flush() override;
+
+    uint64_t packets_seen() const { return d_nSeen; }
+    uint64_t pdus_published() const { return d_nPdu; }
+
+private:
+    decode(bool ifdebug, int batch_frames, int device);
+    bool run_batch();
+
+    bool d_debug;
+    int d_batch;
+    gpu_session d_gpu;
+    enum { S_IDLE, S_COLLECT, S_CLEAN } d_state = S_IDLE;
+    // tags of the packet being collected (lib/decode_impl.cc:77-88)
+    long t_format = 0, t_len = 0, t_nTotal = 0, t_cr = 0, t_mcs = 0, t_ampdu = 0, v_trellis = 0;
+    long t_nProcd = 0;
+    std::vector<float> d_llr;                 // soft bits of the pending packets, back to back
+    std::vector<gr80211_dec_desc> d_desc;     // one per pending packet
+    uint64_t d_nSeen = 0, d_nPdu = 0;
+};
+
+class rx : public block
+{
+public:
+    typedef std::shared_ptr<rx> sptr;
+    // n_rx = 1: inputs {u8 sync, c64} like ieee80211::signal; n_rx = 2: {u8 sync, c64, c64} like signal2.
+    static sptr make(int n_rx = 1, int batch_frames = 4096, int device = 0);
+    ~rx() override;
+
+    void forecast(int noutput_items, gr_vector_int &ninput_items_required) override;
+    int general_work(int noutput_items, gr_vector_int &ninput_items, gr_vector_const_void_star &input_items,
+                     gr_vector_void_star &output_items) override;
+    bool flush() override;
+
+    uint64_t triggers_seen() const { return d_nTrig; }
+    uint64_t frames_decoded() const { return d_nFrames; }
+    uint64_t pdus_published() const { return d_nPdu; }
+
+private:
+    rx(int n_rx, int batch_frames, int device);
+    bool process(bool final);
+
+    struct trigger {
+        uint64_t pos;  // absolute item index of the sync byte
+        float rad, snr, rssi;
+        bool probed;
+        int status, nsamp;
+    };
+    int d_nrx, d_batch;
+    gpu_session d_gpu;
+    std::vector<gr_complex> d_hold[2];  // samples not yet released, both antennas
+    uint64_t d_base = 0;                // absolute item index of d_hold[*][0]
+    uint64_t d_cursor = 0;              // absolute index where the trigger search resumes (lib/signal_impl.cc:75-106)
+    std::vector<trigger> d_trig;
+    size_t d_maxHold;
+    uint64_t d_nTrig = 0, d_nFrames = 0, d_nPdu = 0;
+};
+
+}  // namespace host
+}  // namespace gr80211

@@ -53,7 +53,7 @@ assert FRAME_INFO_DTYPE.itemsize == C.sizeof(FrameInfo) == 112
 assert DEC_DESC_DTYPE.itemsize == C.sizeof(DecDesc) == 40
 
 EXPORTS = [
-    "gr80211_create", "gr80211_destroy", "gr80211_last_error", "gr80211_sync", "gr80211_rx_batch",
+    "gr80211_create", "gr80211_destroy", "gr80211_last_error", "gr80211_sync", "gr80211_rx_batch", "gr80211_signal_batch",
     "gr80211_demod_batch", "gr80211_decode_batch", "gr80211_dev_alloc", "gr80211_dev_free",
     "gr80211_copy_h2d", "gr80211_copy_d2h", "gr80211_set_profiling", "gr80211_last_timing",
     "gr80211_version", "gr80211_table_checksum",
@@ -78,6 +78,7 @@ def load_library():
     L.gr80211_last_error.restype = C.c_char_p
     L.gr80211_sync.argtypes = [vp, vp]
     L.gr80211_rx_batch.argtypes = [vp, vp, vp, C.c_uint64, vp, C.c_int, C.c_uint, vp, C.c_int, vp, vp, vp, vp]
+    L.gr80211_signal_batch.argtypes = [vp, vp, vp, C.c_uint64, vp, C.c_int, C.c_uint, vp, vp]
     L.gr80211_demod_batch.argtypes = [vp, vp, vp, C.c_uint64, vp, C.c_int, C.c_uint, vp, C.POINTER(vp),
                                       C.POINTER(C.c_uint64), vp]
     L.gr80211_decode_batch.argtypes = [vp, vp, C.c_uint64, vp, C.c_int, C.c_uint, vp, C.c_int, vp, vp, vp,
@@ -216,6 +217,18 @@ class RxContext:
             C.c_void_p(info.data_ptr()) if info is not None else None, self._stream())
         self._check(rc, "gr80211_rx_batch")
         return keep
+
+    def signal_batch(self, iq0, iq1, desc, n_frames):
+        """IQ -> per-frame tag records only (L-SIG, format detection, SIG fields).  Returns the info ndarray."""
+        t = self.torch
+        info = t.empty(max(n_frames, 1) * FRAME_INFO_DTYPE.itemsize, dtype=t.uint8, device=self.dev)
+        dp, flags, keep = self._desc_arg(desc)
+        rc = self.lib.gr80211_signal_batch(
+            self.h, C.c_void_p(iq0.data_ptr()), C.c_void_p(iq1.data_ptr()) if iq1 is not None else None,
+            iq0.numel(), dp, n_frames, flags, C.c_void_p(info.data_ptr()), self._stream())
+        self._check(rc, "gr80211_signal_batch")
+        self.sync()
+        return info.cpu().numpy().view(FRAME_INFO_DTYPE)[:n_frames]
 
     def demod_batch(self, iq0, iq1, desc, n_frames):
         """IQ -> LLRs.  Returns (info ndarray, llr ndarray on host)."""

@@ -118,6 +118,18 @@ int gr80211_rx_batch(gr80211_ctx *ctx, const void *d_iq0, const void *d_iq1, uin
                      gr80211_frame_info *d_info, void *stream);
 
 /*
+ * signal/signal2 (and the format detection of demod/demod2) only: L-SIG decode, format detection,
+ * HT-SIG / VHT-SIG-A / VHT-SIG-B decode and channel estimation of every frame, no data symbols.
+ * d_info[i] receives status, L-SIG mcs/len, nsamp (the number of samples `signal` forwards after
+ * L-SIG, lib/signal_impl.cc:126-131) and the frame's modulation record.  A streaming caller uses it
+ * the way the reference chain uses `signal`: to learn how many samples a triggered frame spans before
+ * it looks for the next trigger (lib/signal_impl.cc:75-106,153-160).
+ */
+int gr80211_signal_batch(gr80211_ctx *ctx, const void *d_iq0, const void *d_iq1, uint64_t arena_len,
+                         const gr80211_frame_desc *desc, int n_frames, unsigned flags,
+                         gr80211_frame_info *d_info, void *stream);
+
+/*
  * signal + demod only: IQ -> soft bits in the layout of the demod->decode stream, i.e. for each
  * frame `total` floats in decoder order starting at info.llr_off of an internal LLR arena whose
  * device address is returned in *d_llr (valid until the next call on this context).

@@ -38,3 +38,15 @@ def test_null_context_is_rejected(pkg):
     assert lib.gr80211_sync(None, None) == -1
     assert lib.gr80211_set_profiling(None, 1) == -1
     assert lib.gr80211_last_error(None) == b"null context"
+
+
+def test_host_blocks_library_loads():
+    """The C++ host blocks link against the C-ABI library and load without a GPU; the command-line
+    scheduler rejects a bad invocation before it touches the device."""
+    import subprocess
+    d = os.path.join(ROOT, "fork-gr-ieee80211_amd")
+    assert os.path.exists(os.path.join(d, "libgr80211_host.so")), "run __graft_entry__.build()"
+    ctypes.CDLL(os.path.join(d, "libgr80211_rx.so"), mode=ctypes.RTLD_GLOBAL)
+    ctypes.CDLL(os.path.join(d, "libgr80211_host.so"))
+    p = subprocess.run([os.path.join(d, "gr80211_pump")], capture_output=True, text=True, timeout=60)
+    assert p.returncode == 2 and "usage" in p.stderr

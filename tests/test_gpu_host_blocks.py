@@ -1,0 +1,184 @@
+"""The C++ host blocks (fork-gr-ieee80211_amd/host) driven like GNU Radio drives the reference's blocks:
+streams cut into scheduler-sized windows, tags on the sync byte / first soft bit, messages out.
+Expected messages come from the CPU oracle run frame by frame under a Python model of `signal`'s
+trigger/copy state machine (lib/signal_impl.cc:75-106,153-202)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from util import H22, golden_frames, ref_fixtures
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PUMP = os.path.join(ROOT, "fork-gr-ieee80211_amd", "gr80211_pump")
+ST_DROP_LSIG = 1
+
+
+def run_pump(args):
+    assert os.path.exists(PUMP), "host blocks not built: run __graft_entry__.build()"
+    p = subprocess.run([PUMP] + [str(a) for a in args], capture_output=True, text=True, timeout=170)
+    assert p.returncode == 0, (p.returncode, p.stderr[-2000:])
+    pdus = [bytes.fromhex(l.split()[1]) for l in p.stdout.splitlines() if l.startswith("PDU ")]
+    stat = [l for l in p.stdout.splitlines() if l.startswith("STAT")]
+    return pdus, stat[0] if stat else ""
+
+
+def blob_of(p):
+    n = len(p["mpdu"])
+    return bytes([p["format"], n % 256, n // 256]) + p["mpdu"] + bytes([p["mcs"]])
+
+
+def model_chain(oracle, iq0, iq1, triggers):
+    """What signal -> demod -> decode publish for a stream with tagged sync bytes at `triggers`."""
+    out, cursor, n_frames = [], 0, 0
+    for pos, rad in sorted(triggers):
+        if pos < cursor:
+            continue  # inside the previous frame: the trigger search has not resumed yet
+        if len(iq0) - pos < 224:
+            break
+        r = oracle.rx_frame(iq0, iq1, pos, rad, want_llr=False)
+        if r["status"] == ST_DROP_LSIG:
+            cursor = pos + 80
+            continue
+        span = 224 + max(int(r["frame"].nsamp), 0)
+        end = min(len(iq0), pos + span)
+        r = oracle.rx_frame(iq0[:end], None if iq1 is None else iq1[:end], pos, rad, want_llr=False)
+        out += [blob_of(p) for p in r["pdus"]]
+        n_frames += 1
+        cursor = pos + span
+    return out, n_frames
+
+
+def write_stream(tmp_path, iq0, iq1, triggers):
+    f0 = tmp_path / "iq0.bin"
+    iq0.astype(np.complex64).tofile(f0)
+    files = [f0]
+    if iq1 is not None:
+        f1 = tmp_path / "iq1.bin"
+        iq1.astype(np.complex64).tofile(f1)
+        files.append(f1)
+    tf = tmp_path / "trig.txt"
+    with open(tf, "w") as fh:
+        for pos, rad in triggers:
+            fh.write("%d %.9g 30.0 -40.0\n" % (pos, rad))
+    return tf, files
+
+
+def siso_stream(noise_sigma, seed):
+    rng = np.random.default_rng(seed)
+    frames = [f for f in golden_frames() if f["nss"] == 1]
+    parts, triggers, pos = [], [], 0
+    for k, f in enumerate(frames):
+        iq = f["iq"][0]
+        parts.append(iq)
+        triggers.append((pos + f["sync_idx"], f["rad"]))
+        if k == 0:
+            triggers.append((pos + f["sync_idx"] + 900, 0.0))   # inside frame 0: must be ignored
+        if k == 2:
+            triggers.append((pos + 100, 0.0))                    # on the silence before frame 2: L-SIG fails
+        pos += len(iq)
+    iq0 = np.concatenate(parts + [np.zeros(500, np.complex64)]).astype(np.complex64)
+    if noise_sigma > 0:
+        iq0 = (iq0 + noise_sigma * (rng.standard_normal(len(iq0)) + 1j * rng.standard_normal(len(iq0)))).astype(np.complex64)
+    return iq0, triggers, frames
+
+
+@pytest.mark.parametrize("chunk,batch", [(4096, 1000), (777, 2), (8192, 1)])
+def test_rx_block_siso_stream(tmp_path, oracle, chunk, batch):
+    iq0, triggers, frames = siso_stream(0.002, 6)
+    want, n_frames = model_chain(oracle, iq0, None, triggers)
+    assert n_frames == len(frames)
+    tf, files = write_stream(tmp_path, iq0, None, triggers)
+    got, stat = run_pump(["rx", 1, chunk, batch, tf] + files)
+    assert "frames=%d " % n_frames in stat + " ", stat
+    assert got == want
+    # every transmitted MPDU came back, in stream order
+    mpdus = [p[3:-1] for p in got]
+    assert mpdus == [f["mpdu"] for f in frames]
+
+
+def test_rx_block_false_lsig_swallows_stream(tmp_path, oracle):
+    """With this noise seed the tagged sync byte on silence passes the L-SIG check by chance and announces a
+    frame longer than the rest of the stream: like `signal`, the block must then ignore every later trigger and
+    decode the (garbage) frame with the samples it has when the stream ends."""
+    iq0, triggers, frames = siso_stream(0.002, 5)
+    want, n_frames = model_chain(oracle, iq0, None, triggers)
+    assert n_frames == 3 and len(want) == 2
+    tf, files = write_stream(tmp_path, iq0, None, triggers)
+    got, stat = run_pump(["rx", 1, 2048, 4, tf] + files)
+    assert "frames=3 " in stat + " ", stat
+    assert got == want
+
+
+def test_rx_block_two_antennas(tmp_path, oracle):
+    rng = np.random.default_rng(9)
+    parts, triggers, pos, sent = [], [], 0, []
+    for f in [f for f in golden_frames() if f["nss"] == 2]:
+        rx = (H22 @ f["iq"]).astype(np.complex64)
+        parts.append(rx)
+        triggers.append((pos + f["sync_idx"], f["rad"]))
+        sent.append(f["mpdu"])
+        pos += rx.shape[1]
+    name, ants, sidx = ref_fixtures()[1]
+    parts.append(np.stack(ants))
+    triggers.append((pos + sidx, 0.0))
+    iq = np.concatenate(parts, axis=1)
+    iq = (iq + 0.001 * (rng.standard_normal(iq.shape) + 1j * rng.standard_normal(iq.shape))).astype(np.complex64)
+    want, n_frames = model_chain(oracle, iq[0], iq[1], triggers)
+    assert n_frames == len(triggers)
+    tf, files = write_stream(tmp_path, iq[0], iq[1], triggers)
+    got, stat = run_pump(["rx", 2, 3000, 3, tf] + files)
+    assert got == want
+    assert [p[3:-1] for p in got][: len(sent)] == sent
+
+
+def test_rx_block_reference_fixture(tmp_path, oracle):
+    from util import ref_fixture_mpdu
+    name, ants, sidx = ref_fixtures()[0]
+    tf, files = write_stream(tmp_path, ants[0], None, [(sidx, 0.0)])
+    got, stat = run_pump(["rx", 1, 1024, 16, tf] + files)
+    assert len(got) == 1 and got[0][3:-1] == ref_fixture_mpdu()
+    assert got[0][0] == 0 and got[0][-1] == 0  # legacy, 6 Mb/s
+
+
+@pytest.mark.parametrize("chunk,batch", [(4096, 1000), (1000, 2)])
+def test_decode_block_stream(tmp_path, pkg, rxctx, oracle, chunk, batch):
+    """decode drop-in: soft-bit stream with the tags demod attaches to a packet's first item."""
+    import torch
+    from util import build_arena
+    frames = [f for f in golden_frames() if f["nss"] == 1]
+    iq0, iq1, sync, navail = build_arena([([f["iq"][0]], f["sync_idx"]) for f in frames])
+    rads = np.array([f["rad"] for f in frames], np.float32)
+    desc = rxctx.make_desc(sync, navail, rad=rads)
+    info, llr = rxctx.demod_batch(torch.from_numpy(iq0).cuda(), None, desc, len(frames))
+    stream, tags, want = [], [], []
+    junk = np.full(37, 0.25, np.float32)  # untagged items between packets are passed over
+    at = 0
+    for i, f in enumerate(frames):
+        assert int(info["status"][i]) == 0
+        tot = int(info["total"][i])
+        o = int(info["llr_off"][i])
+        stream.append(junk)
+        at += len(junk)
+        tags.append((at, int(info["format"][i]), int(info["len"][i]), tot, int(info["cr"][i]), int(info["mcs"][i]),
+                     int(info["ampdu"][i]), int(info["trellis"][i])))
+        stream.append(llr[o:o + tot])
+        at += tot
+        ref = oracle.rx_frame(iq0[: int(sync[i]) + int(navail[i])], None, int(sync[i]), float(rads[i]), want_llr=False)
+        want += [blob_of(p) for p in ref["pdus"]]
+    # an oversize packet is skipped whole (lib/decode_impl.cc:93-97)
+    tags.append((at, 0, 5000, 64, 0, 0, 0, 40022))
+    stream.append(np.zeros(64, np.float32))
+    lf = tmp_path / "llr.bin"
+    np.concatenate(stream).astype(np.float32).tofile(lf)
+    tf = tmp_path / "tags.txt"
+    with open(tf, "w") as fh:
+        for t in tags:
+            fh.write(" ".join(str(v) for v in t) + "\n")
+    got, stat = run_pump(["decode", chunk, batch, tf, lf])
+    assert got == want
+    assert "packets=%d " % len(tags) in stat + " ", stat
+    assert [p[3:-1] for p in got] == [f["mpdu"] for f in frames]
