@@ -29,41 +29,56 @@ WORKLOADS = {
     "vht_mcs8_1500B_snr30": (2, 8, 1, 1496, 30.0, 32924),
     "vht_mcs4_1500B_snr30": (2, 4, 1, 1496, 30.0, 57884),
     "l_mcs0_1000B_snr30": (0, 0, 1, 1000, 30.0, 218664),
+    "ht_mcs15_2x2_1500B_snr30": (1, 15, 2, 1500, 30.0, 45084),
 }
+# frames per GPU the configuration list quotes for each workload, and trellis steps per frame
+DEFAULT_FRAMES = {"vht_mcs8_1500B_snr30": 100000, "vht_mcs4_1500B_snr30": 10000, "l_mcs0_1000B_snr30": 10000,
+                  "ht_mcs15_2x2_1500B_snr30": 50000}
+TRELLIS_STEPS = {"vht_mcs8_1500B_snr30": 12168, "vht_mcs4_1500B_snr30": 12168, "l_mcs0_1000B_snr30": 8022,
+                 "ht_mcs15_2x2_1500B_snr30": 12022}
+H22 = ((1.0, 0.5j), (0.4, -1.0))  # fixed well-conditioned 2x2 channel of the two-antenna workload
 HBM_PEAK_GBS = 8000.0
 
 
 def build_corpus(torch, tx, wl, n_frames, n_unique, seed, dev):
+    """Returns ([arena per antenna], sync, navail, expected blobs, payload index per frame, samples per frame)."""
     fmt, mcs, nss, nbytes, snr_db, _ = WORKLOADS[wl]
     rng = np.random.default_rng(80211 + seed)
     sigs, blobs = [], []
     for _ in range(n_unique):
         mpdu = tx.make_mpdu(nbytes, rng)
         sig, m = tx.gen_frame(fmt, mcs, nss, mpdu)
-        sigs.append((sig[0] * 12.0).astype(np.complex64))
+        sig = np.asarray(sig) * (12.0 * np.sqrt(nss))
+        if nss == 2:
+            sig = np.array(H22, dtype=np.complex128) @ sig
+        sigs.append(sig.astype(np.complex64))
         blobs.append(bytes([fmt, nbytes % 256, nbytes // 256]) + mpdu + bytes([mcs]))
-    L = len(sigs[0])
-    uniq = torch.from_numpy(np.stack(sigs)).to(dev)
-    power = float(np.mean(np.abs(np.stack(sigs)) ** 2))
+    L = sigs[0].shape[1]
+    stack = np.stack(sigs)  # [unique][antenna][L]
+    power = float(np.mean(np.abs(stack) ** 2))
     sigma = float(np.sqrt(power / (10.0 ** (snr_db / 10.0)) / 2.0))
     gen = torch.Generator(device=dev)
     gen.manual_seed(1 + seed)
     idx = torch.arange(n_frames, device=dev) % n_unique
-    arena = torch.empty(n_frames * L + 64, dtype=torch.complex64, device=dev)
-    view = torch.view_as_real(arena[: n_frames * L].view(n_frames, L))
-    chunk = 8192
-    for s in range(0, n_frames, chunk):
-        e = min(n_frames, s + chunk)
-        noise = torch.randn((e - s, L, 2), generator=gen, device=dev, dtype=torch.float32) * sigma
-        view[s:e] = torch.view_as_real(uniq[idx[s:e]]) + noise
-    arena[n_frames * L:] = 0
+    arenas = []
+    for a in range(nss):
+        uniq = torch.from_numpy(np.ascontiguousarray(stack[:, a, :])).to(dev)
+        arena = torch.empty(n_frames * L + 64, dtype=torch.complex64, device=dev)
+        view = torch.view_as_real(arena[: n_frames * L].view(n_frames, L))
+        chunk = 8192
+        for s in range(0, n_frames, chunk):
+            e = min(n_frames, s + chunk)
+            noise = torch.randn((e - s, L, 2), generator=gen, device=dev, dtype=torch.float32) * sigma
+            view[s:e] = torch.view_as_real(uniq[idx[s:e]]) + noise
+        arena[n_frames * L:] = 0
+        arenas.append(arena)
     sync = (np.arange(n_frames, dtype=np.uint64) * L + 176)
     navail = np.full(n_frames, L - 176, dtype=np.uint32)
     exp = torch.from_numpy(np.frombuffer(b"".join(blobs), dtype=np.uint8).reshape(n_unique, -1).copy()).to(dev)
-    return arena, sync, navail, exp, idx, L
+    return arenas, sync, navail, exp, idx, L
 
 
-def cpu_baseline(arena_host, sync, navail, n_sample, gpu_blobs, budget_s=12.0):
+def cpu_baseline(arena_host, arena1_host, sync, navail, n_sample, gpu_blobs, budget_s=12.0):
     """Times the CPU oracle (scalar port of the reference path) on the first frames of the same corpus,
     first on one thread and then on every core of this process's CPU share (frames sharded over threads;
     the oracle call releases the GIL), and checks the GPU output against it frame by frame."""
@@ -76,7 +91,8 @@ def cpu_baseline(arena_host, sync, navail, n_sample, gpu_blobs, budget_s=12.0):
         n_done, samples, mism, n_ok = 0, 0, 0, 0
         for i in range(lo, hi):
             end = int(sync[i]) + int(navail[i])
-            r = O.rx_frame(arena_host[:end], None, int(sync[i]), 0.0, want_llr=False)
+            r = O.rx_frame(arena_host[:end], None if arena1_host is None else arena1_host[:end], int(sync[i]), 0.0,
+                           want_llr=False)
             n_done += 1
             samples += int(navail[i]) + 176
             n_ok += r["n_pdu"]
@@ -129,10 +145,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--frames", type=int, default=100000, help="frames per GPU")
+    ap.add_argument("--frames", type=int, default=0, help="frames per GPU (0 = the workload's configured size)")
     ap.add_argument("--workload", default="vht_mcs8_1500B_snr30", choices=sorted(WORKLOADS))
     ap.add_argument("--unique", type=int, default=64, help="distinct payloads in the corpus")
     ap.add_argument("--cpu-frames", type=int, default=48000, help="frames timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--host-buffers", action="store_true", help="also time one step with PCIe transfers included")
     ap.add_argument("--profile-steps", type=int, default=3, help="extra untimed steps with per-kernel HIP events")
     args = ap.parse_args()
 
@@ -154,8 +171,9 @@ def main():
     pkg = importlib.import_module("fork-gr-ieee80211_amd")
     tx = pkg.txgen
     ctx = pkg.RxContext(local)
-    n = args.frames
-    arena, sync, navail, exp, idx, L = build_corpus(torch, tx, args.workload, n, args.unique, rank, dev)
+    n = args.frames if args.frames > 0 else DEFAULT_FRAMES[args.workload]
+    arenas, sync, navail, exp, idx, L = build_corpus(torch, tx, args.workload, n, args.unique, rank, dev)
+    arena, arena1 = arenas[0], (arenas[1] if len(arenas) > 1 else None)
     fmt, mcs, nss, nbytes, snr_db, b_alg = WORKLOADS[args.workload]
     desc = torch.from_numpy(ctx.make_desc(sync, navail).view(np.uint8).reshape(-1)).to(dev)
     blob_len = exp.shape[1]
@@ -167,7 +185,7 @@ def main():
     gathered = {}
 
     def step():
-        ctx.rx_batch_into(arena, None, desc, n, out, out_len, n_pdu)
+        ctx.rx_batch_into(arena, arena1, desc, n, out, out_len, n_pdu)
         if world > 1:
             # the one exchange step of the path: decoded MPDUs travel to rank 0 (RCCL gather over xGMI)
             gathered["out"], gathered["len"] = shard.gather_pdus(out, out_len, dst=0)
@@ -203,7 +221,7 @@ def main():
         ctx.set_profiling(True)
         acc = {}
         for _ in range(args.profile_steps):
-            ctx.rx_batch_into(arena, None, desc, n, out, out_len, n_pdu)
+            ctx.rx_batch_into(arena, arena1, desc, n, out, out_len, n_pdu)
             for k, v in ctx.last_timing().items():
                 acc[k] = acc.get(k, 0.0) + v
         ctx.set_profiling(False)
@@ -217,7 +235,7 @@ def main():
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": args.workload, "frames_per_gpu": n, "samples_per_frame": L,
-                   "format": "VHT" if fmt == 2 else "HT" if fmt == 1 else "L", "mcs": mcs, "n_rx": 1,
+                   "format": "VHT" if fmt == 2 else "HT" if fmt == 1 else "L", "mcs": mcs, "n_rx": nss,
                    "psdu_bytes": nbytes + 4 if fmt == 2 else nbytes, "snr_db": snr_db, "unique_payloads": args.unique,
                    "parallelism": "frames sharded per GPU, RCCL gather of MPDUs" if world > 1 else "single GPU"},
         "psdu": {"frames": n, "fcs_ok": n_ok, "bit_exact_vs_tx": bitexact, "fcs_ok_but_wrong": wrong},
@@ -229,8 +247,7 @@ def main():
     if dec_ms > 0:
         timing["decode"] = dec_ms
         achieved = b_alg * n / (dec_ms * 1e-3) / 1e9
-        steps_per_frame = {"vht_mcs8_1500B_snr30": 12168, "vht_mcs4_1500B_snr30": 12168,
-                           "l_mcs0_1000B_snr30": 8022}[args.workload]
+        steps_per_frame = TRELLIS_STEPS[args.workload]
         res["roofline"] = {"bound": "hbm", "kernel": "k_decode", "achieved": achieved, "peak": HBM_PEAK_GBS,
                            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                            "traffic": measured_traffic(args.workload, n),
@@ -239,13 +256,31 @@ def main():
                                    "not by HBM; it also reads the materialised soft bits and writes/reads the "
                                    "survivor words, which the per-frame figure (IQ in + PSDU out) does not count",
                            "acs_state_updates_per_s": 64.0 * steps_per_frame * n / (dec_ms * 1e-3)}
+    if rank == 0 and world == 1 and args.host_buffers:
+        # the same step when the boundary hands over host buffers: IQ travels H2D, PDUs travel D2H (pinned memory)
+        h_in = [a.cpu().pin_memory() for a in arenas]
+        h_out = torch.empty(out.shape, dtype=out.dtype).pin_memory()
+        h_len = torch.empty(out_len.shape, dtype=out_len.dtype).pin_memory()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for a, h in zip(arenas, h_in):
+            a.copy_(h, non_blocking=True)
+        ctx.rx_batch_into(arena, arena1, desc, n, out, out_len, n_pdu)
+        h_out.copy_(out, non_blocking=True)
+        h_len.copy_(out_len, non_blocking=True)
+        torch.cuda.synchronize()
+        dth = time.perf_counter() - t0
+        res["host_buffers"] = {"value": n * L / dth / 1e6, "unit": "Msamples/s", "ms_per_step": dth * 1e3,
+                               "note": "IQ arena H2D + step + PDU slots D2H over PCIe, pinned host memory; not the headline"}
+        del h_in, h_out, h_len
     if rank == 0 and args.cpu_frames > 0 and world == 1:
         ns = min(args.cpu_frames, n)
         host = arena[: ns * L + 64].cpu().numpy()
+        host1 = arena1[: ns * L + 64].cpu().numpy() if arena1 is not None else None
         lens = out_len[:ns].cpu().numpy()
         rows = out[:ns].cpu().numpy()
         gpu_blobs = [bytes(rows[i, : lens[i]]) for i in range(ns)]
-        res["cpu_baseline"] = cpu_baseline(host, sync, navail, ns, gpu_blobs)
+        res["cpu_baseline"] = cpu_baseline(host, host1, sync, navail, ns, gpu_blobs)
     if rank == 0:
         print(json.dumps(res))
     if world > 1:

@@ -15,7 +15,8 @@ import bench  # noqa: E402
 pkg = importlib.import_module("fork-gr-ieee80211_amd")
 dev = torch.device("cuda", 0)
 n = 100000
-arena, sync, navail, exp, idx, L = bench.build_corpus(torch, pkg.txgen, "vht_mcs8_1500B_snr30", n, 64, 0, dev)
+arenas, sync, navail, exp, idx, L = bench.build_corpus(torch, pkg.txgen, "vht_mcs8_1500B_snr30", n, 64, 0, dev)
+arena = arenas[0]
 ctx0 = pkg.RxContext(0)
 desc_np = ctx0.make_desc(sync, navail)
 blob_len = exp.shape[1]
