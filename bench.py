@@ -162,11 +162,18 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (WORLD_SIZE=%d)" % (args.gpus, world))
+    # GR80211_BENCH_BACKEND=gloo rehearses the N > 1 path where RCCL cannot run (several ranks on one GPU):
+    # ranks then share devices round-robin and every collective gets host tensors
+    backend = os.environ.get("GR80211_BENCH_BACKEND", "nccl")
+    local = local % max(1, torch.cuda.device_count()) if backend == "gloo" else local
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     pkg = importlib.import_module("fork-gr-ieee80211_amd")
     tx = pkg.txgen
@@ -178,19 +185,30 @@ def main():
     desc = torch.from_numpy(ctx.make_desc(sync, navail).view(np.uint8).reshape(-1)).to(dev)
     blob_len = exp.shape[1]
     out_stride = ((blob_len + 4 + 63) // 64) * 64
-    out = torch.zeros((n, out_stride), dtype=torch.uint8, device=dev)
-    out_len = torch.zeros(n, dtype=torch.int32, device=dev)
-    n_pdu = torch.zeros(n, dtype=torch.int32, device=dev)
+    # two sets of outputs: at N > 1 the gather of one batch overlaps the kernels of the next
+    depth = 2 if world > 1 else 1
+    outs = [(torch.zeros((n, out_stride), dtype=torch.uint8, device=dev),
+             torch.zeros(n, dtype=torch.int32, device=dev),
+             torch.zeros(n, dtype=torch.int32, device=dev)) for _ in range(depth)]
+    out, out_len, n_pdu = outs[0]
     shard = importlib.import_module("fork-gr-ieee80211_amd.shard")
-    gathered = {}
+    gatherer = shard.PduGather(n, out_stride, dev, dst=0, depth=depth) if world > 1 else None
+    counter = [0]
 
     def step():
-        ctx.rx_batch_into(arena, arena1, desc, n, out, out_len, n_pdu)
-        if world > 1:
+        slot = counter[0] % depth
+        counter[0] += 1
+        o, ol, npd = outs[slot]
+        if gatherer is not None:
+            gatherer.wait(slot)  # the batch that used these tensors two steps ago has left
+        ctx.rx_batch_into(arena, arena1, desc, n, o, ol, npd)
+        if gatherer is not None:
             # the one exchange step of the path: decoded MPDUs travel to rank 0 (RCCL gather over xGMI)
-            gathered["out"], gathered["len"] = shard.gather_pdus(out, out_len, dst=0)
+            gatherer.start(slot, o, ol)
 
     def fence():
+        if gatherer is not None:
+            gatherer.finish()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -204,7 +222,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 

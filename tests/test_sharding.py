@@ -45,6 +45,64 @@ def _worker(rank, world, port, n_total, q):
     dist.destroy_process_group()
 
 
+def _worker_pipeline(rank, world, port, n_local, q):
+    """Three batches through the double-buffered asynchronous gather."""
+    sys.path.insert(0, ROOT)
+    import importlib
+    shard = importlib.import_module("fork-gr-ieee80211_amd.shard")
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    stride, depth = 8, 2
+    g = shard.PduGather(n_local, stride, torch.device("cpu"), dst=0, depth=depth)
+    outs = [(torch.zeros((n_local, stride), dtype=torch.uint8), torch.zeros(n_local, dtype=torch.int32))
+            for _ in range(depth)]
+    ok = True
+    seen = []
+    for step in range(3):
+        slot = step % depth
+        res = g.wait(slot)
+        if res[0] is not None:
+            seen.append((step - depth, res[0].clone(), res[1].clone()))
+        o, ol = outs[slot]
+        o[:, 0] = rank
+        o[:, 1] = step
+        o[:, 2] = torch.arange(n_local, dtype=torch.uint8)
+        ol[:] = 3 + step
+        g.start(slot, o, ol)
+    for slot in ((3 % depth), ((3 + 1) % depth)):
+        res = g.wait(slot)
+        if res[0] is not None:
+            seen.append((None, res[0].clone(), res[1].clone()))
+    if rank == 0:
+        ok = len(seen) == 3
+        steps_seen = sorted(int(a[0, 1]) for _, a, _ in seen)
+        ok = ok and steps_seen == [0, 1, 2]
+        for _, a, l in seen:
+            st = int(a[0, 1])
+            for r in range(world):
+                blk = a[r * n_local:(r + 1) * n_local]
+                ok = ok and bool((blk[:, 0] == r).all()) and bool((blk[:, 1] == st).all())
+                ok = ok and bool((blk[:, 2] == torch.arange(n_local, dtype=torch.uint8)).all())
+            ok = ok and bool((l == 3 + st).all())
+        q.put(bool(ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_pipelined_gather_two_ranks_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_pipeline, args=(r, 2, port, 40, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert q.get(timeout=5) is True
+
+
 def test_shard_ranges_cover_everything(pkg):
     import importlib
     shard = importlib.import_module("fork-gr-ieee80211_amd.shard")
