@@ -55,3 +55,66 @@ def test_configured_batch_round_trip(pkg, rxctx, oracle, workload, n_oracle):
         ref = oracle.rx_frame(h0, h1, 176, 0.0, want_llr=False)
         got = bytes(out[i, : lens[i]].cpu().numpy())
         assert got == ref["blob"], (workload, int(i))
+
+
+@pytest.mark.parametrize("two_ant,n_frames", [(False, 125000), (True, 20000)])
+def test_mixed_capture_corpus_replicated(pkg, rxctx, oracle, two_ant, n_frames):
+    """Mixed L/HT/VHT corpus (the reference's IQ fixtures + the Python-reference frames) replicated round-robin
+    to a full shard: every replica must give exactly what the oracle gives for its source frame.  Exercises the
+    group scheduler with many (code rate, length) classes and partly filled groups."""
+    import torch
+    from util import H22, golden_frames, ref_fixtures
+    dev = torch.device("cuda", 0)
+    srcs = []  # (antenna arrays, sync index, rad)
+    if two_ant:
+        for f in golden_frames():
+            if f["nss"] == 2:
+                rx = (H22 @ f["iq"]).astype(np.complex64)
+                srcs.append(([rx[0], rx[1]], f["sync_idx"], f["rad"]))
+        name, ants, sidx = ref_fixtures()[1]
+        srcs.append((ants, sidx, 0.0))
+    else:
+        for f in golden_frames():
+            if f["nss"] == 1:
+                srcs.append(([f["iq"][0].astype(np.complex64)], f["sync_idx"], f["rad"]))
+        name, ants, sidx = ref_fixtures()[0]
+        srcs.append((ants, sidx, 0.0))
+    nant = 2 if two_ant else 1
+    blk = [np.concatenate([s[0][a] for s in srcs]) for a in range(nant)]
+    blk_len = len(blk[0])
+    offs, pos = [], 0
+    for s in srcs:
+        offs.append(pos + s[1])
+        pos += len(s[0][0])
+    navail_u = [len(s[0][0]) - s[1] for s in srcs]
+    # what the oracle says for each source frame, restricted like the descriptor restricts the GPU
+    want = []
+    for k, s in enumerate(srcs):
+        end = offs[k] + navail_u[k]
+        r = oracle.rx_frame(blk[0][:end], blk[1][:end] if two_ant else None, offs[k], s[2], want_llr=False)
+        want.append(r["blob"])
+    assert sum(1 for w in want if len(w) > 0) == len(srcs)
+    u = len(srcs)
+    reps = (n_frames + u - 1) // u
+    arenas = [torch.cat([torch.from_numpy(b).to(dev).repeat(reps), torch.zeros(64, dtype=torch.complex64, device=dev)])
+              for b in blk]
+    k = np.arange(n_frames)
+    sync = (k // u).astype(np.uint64) * np.uint64(blk_len) + np.array(offs, dtype=np.uint64)[k % u]
+    navail = np.array(navail_u, dtype=np.uint32)[k % u]
+    rads = np.array([s[2] for s in srcs], dtype=np.float32)[k % u]
+    desc = torch.from_numpy(rxctx.make_desc(sync, navail, rad=rads).view(np.uint8).reshape(-1)).to(dev)
+    stride = 1536
+    out = torch.zeros((n_frames, stride), dtype=torch.uint8, device=dev)
+    out_len = torch.zeros(n_frames, dtype=torch.int32, device=dev)
+    n_pdu = torch.zeros(n_frames, dtype=torch.int32, device=dev)
+    rxctx.rx_batch_into(arenas[0], arenas[1] if two_ant else None, desc, n_frames, out, out_len, n_pdu)
+    rxctx.sync()
+    exp = torch.zeros((u, stride), dtype=torch.uint8)
+    exp_len = torch.zeros(u, dtype=torch.int32)
+    for i, w in enumerate(want):
+        exp[i, : len(w)] = torch.frombuffer(bytearray(w), dtype=torch.uint8)
+        exp_len[i] = len(w)
+    idx = torch.from_numpy(k % u).to(dev)
+    assert torch.equal(out_len, exp_len.to(dev)[idx])
+    assert torch.equal(out, exp.to(dev)[idx])
+    assert int(n_pdu.sum().item()) == n_frames
