@@ -420,4 +420,9 @@ int gr80211_last_timing(gr80211_ctx *c, float *ms, int n)
     return GR80211_OK;
 }
 
+#ifdef GR80211_TIMELINE
+// Debug build only (not declared in the public header): per-group time stamps of the last k_decode launch.
+int gr80211_debug_timeline(unsigned long long *dst, int n_groups) { return gr80211::read_timeline(dst, n_groups); }
+#endif
+
 }  // extern "C"

@@ -49,6 +49,9 @@ void launch_traceback(const uint32_t *dec, const gr80211_frame_info *info, const
 void launch_decode(const float *llr, const gr80211_frame_info *info, const int32_t *slot_frame,
                    const GroupInfo *groups, int n_groups, uint32_t *dec, uint32_t *bitsw, uint8_t *out, int out_stride,
                    int32_t *out_len, int32_t *n_pdu, uint8_t *bits_out, int bits_stride, hipStream_t s);
+#ifdef GR80211_TIMELINE
+int read_timeline(unsigned long long *dst, int n_groups);
+#endif
 void launch_clear_outputs(int32_t *out_len, int32_t *n_pdu, int n, hipStream_t s);
 
 }  // namespace gr80211

@@ -1185,7 +1185,19 @@ __device__ __forceinline__ void viterbi_group(const float *__restrict__ llr, uns
 #pragma unroll
     for (int i = 0; i < 64; i++) A[i] = i == 0 ? 0.0f : NEG_INIT;
     const float *row = tile + lane * TILE_STRIDE;
+#ifndef GR80211_PRIO_SHIFT
+#define GR80211_PRIO_SHIFT 13
+#endif
+    // Two waves that share a SIMD are served oldest first: the older one runs at the speed of a wave that has
+    // the SIMD to itself and the younger one is left to finish alone, at a lone wave's poor issue rate.  The
+    // waves therefore trade priority in time slices of 2^GR80211_PRIO_SHIFT ticks of the 100-MHz clock (both
+    // read the same clock; the wave slot number tells them apart), so that both stay paired until the end.
+    const unsigned slot_parity = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (3 << 11)) & 1u;  // HW_ID.wave_id
     for (int ch = 0; ch < nchunks; ch++) {
+        if ((((unsigned)(__builtin_amdgcn_s_memrealtime() >> GR80211_PRIO_SHIFT)) ^ slot_parity) & 1u)
+            __builtin_amdgcn_s_setprio(2);
+        else
+            __builtin_amdgcn_s_setprio(0);
         __syncthreads();
         const int c0 = ch * CH + lane;
         // 64 rows (frames) x 64 columns, transposed through LDS.  Each row is one LDS-DMA load
@@ -1462,6 +1474,15 @@ __global__ __launch_bounds__(64) void k_traceback(const uint32_t *__restrict__ d
 // waves still run the add-compare-select recursion, so the memory-bound walk hides behind the
 // VALU-bound recursion instead of following it as a second kernel.
 // =========================================================================================
+#ifdef GR80211_TIMELINE
+// Debug build only: per group {start, end of forward pass, end, hardware id} in 100-MHz ticks.
+__device__ unsigned long long g_timeline[4 * 8192];
+int read_timeline(unsigned long long *dst, int n_groups)
+{
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_timeline), sizeof(unsigned long long) * 4 * (size_t)n_groups);
+}
+#endif
+
 __global__ __launch_bounds__(64) void k_decode(const float *__restrict__ llr, const gr80211_frame_info *__restrict__ info,
                                                const int32_t *__restrict__ slot_frame,
                                                const GroupInfo *__restrict__ groups, int n_groups,
@@ -1472,6 +1493,12 @@ __global__ __launch_bounds__(64) void k_decode(const float *__restrict__ llr, co
     const int g = blockIdx.x;
     if (g >= n_groups) return;
     const int lane = threadIdx.x;
+#ifdef GR80211_TIMELINE
+    if (lane == 0 && g < 8192) {
+        g_timeline[4 * g] = wall_clock64();
+        g_timeline[4 * g + 3] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));  // HW_ID
+    }
+#endif
     __shared__ float tile[64 * TILE_STRIDE];
     const GroupInfo gi = groups[g];
     const int fr = slot_frame[g * 64 + lane];
@@ -1486,11 +1513,18 @@ __global__ __launch_bounds__(64) void k_decode(const float *__restrict__ llr, co
     }
     // every lane reads back only survivor words it stored itself; drain the stores first
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_setprio(3);  // the walk back is a short dependent chain between long memory waits
+#ifdef GR80211_TIMELINE
+    if (lane == 0 && g < 8192) g_timeline[4 * g + 1] = wall_clock64();
+#endif
     __syncthreads();
     uint32_t *s_crc = reinterpret_cast<uint32_t *>(tile);  // the LLR tile is dead from here on
     for (int i = lane; i < 256; i += 64) s_crc[i] = c_tab.crc[i];
     __syncthreads();
     traceback_group(dec, info, gi, fr, lane, s_crc, bitsw, out, out_stride, out_len, n_pdu, bits_out, bits_stride);
+#ifdef GR80211_TIMELINE
+    if (lane == 0 && g < 8192) g_timeline[4 * g + 2] = wall_clock64();
+#endif
 }
 
 __global__ void k_clear_outputs(int32_t *a, int32_t *b, int n)
