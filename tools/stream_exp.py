@@ -26,6 +26,7 @@ out_len = torch.zeros(n, dtype=torch.int32, device=dev)
 n_pdu = torch.zeros(n, dtype=torch.int32, device=dev)
 for S in [int(a) for a in sys.argv[1:]] or [1, 2, 4]:
     ctxs = [pkg.RxContext(0) for _ in range(S)]
+    streams = [torch.cuda.Stream() for _ in range(S)]  # the binding launches on torch's current stream
     bounds = [(n * i // S // 64 * 64 if i < S else n) for i in range(S + 1)]
     bounds[S] = n
     descs = [torch.from_numpy(desc_np[bounds[i]:bounds[i + 1]].view(np.uint8).reshape(-1).copy()).to(dev) for i in range(S)]
@@ -33,7 +34,8 @@ for S in [int(a) for a in sys.argv[1:]] or [1, 2, 4]:
     def step():
         for i in range(S):
             s, e = bounds[i], bounds[i + 1]
-            ctxs[i].rx_batch_into(arena, None, descs[i], e - s, out[s:e], out_len[s:e], n_pdu[s:e])
+            with torch.cuda.stream(streams[i]):
+                ctxs[i].rx_batch_into(arena, None, descs[i], e - s, out[s:e], out_len[s:e], n_pdu[s:e])
 
     step()
     torch.cuda.synchronize()
