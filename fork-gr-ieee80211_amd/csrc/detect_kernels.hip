@@ -1,0 +1,590 @@
+// Frame detection on MI355X: the work of presiso -> trigger -> sync of the reference's receive flowgraph
+// (examples/presiso.grc:68-137,218-229; lib/trigger_impl.cc:59-117; lib/sync_impl.cc:61-196) over a whole
+// capture at once.  gfx950, wave64.
+//
+// The three blocks are sequential state machines over the sample stream; here they become
+//   k_det_ac      one pass over the samples (the HBM-bound part): the normalised 16-lag autocorrelation of
+//                 presiso, thresholded at trigger's 0.3 into one bit per sample;
+//   k_det_edges   rising / falling edges of that bit stream = trigger's plateaus ("runs"), in order;
+//   k_det_trigger trigger's plateau counter / 80-sample countdown and sync's "111 items consumed per
+//                 trigger" rule, replayed per chain of runs that are close enough to influence each other;
+//   k_det_sync    per trigger: the conjugate average sync would hold at that moment, the 64-lag L-LTF
+//                 autocorrelation over 111 positions, its 80 % shoulder midpoint, CFO, SNR, RSSI;
+//   k_det_emit    the sync bytes that were produced, in stream order, as frame descriptors.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "detect_kernels.h"
+
+namespace gr80211 {
+
+namespace {
+
+constexpr int AC_TILE = 2048;   // samples per workgroup of k_det_ac
+constexpr int AC_HALO = 80;     // 63 (power window) + 16 (lag) rounded up
+constexpr int AC_THREADS = 256;
+constexpr int AC_PER_THREAD = AC_TILE / AC_THREADS;  // 8
+constexpr float PLATEAU_AC = 0.3f;   // lib/trigger_impl.cc:78
+constexpr int PLATEAU_LEN = 20;      // lib/trigger_impl.cc:87
+constexpr int COUNT_DOWN = 80;       // lib/trigger_impl.cc:91
+constexpr int SYNC_BUF = 240;        // SYNC_MAX_BUF_LEN, lib/sync_impl.h:30
+constexpr int SYNC_RES = SYNC_BUF - 128 - 1;  // SYNC_MAX_RES_LEN = 111, lib/sync_impl.h:31
+// A run can only be influenced by what happened before it if the previous run ended less than this many samples
+// before its own 21st sample: a countdown started in the previous run fires at most 79 samples after that run's
+// last sample and sync skips the 111 items that follow a trigger byte, so from 20 + 79 + 111 = 210 samples on
+// neither the countdown, nor the skipped items, nor the conjugate value sync holds can reach into this run.
+constexpr long long INDEPENDENT_GAP = 256;
+
+struct c32d {
+    float x, y;
+};
+
+__device__ __forceinline__ c32d ld(const c32d *x, long long i, long long n)
+{
+    c32d z;
+    z.x = 0.0f;
+    z.y = 0.0f;
+    return (i < 0 || i >= n) ? z : x[i];  // before the capture: the zero history GNU Radio blocks start with
+}
+
+// |z| as the C library's hypotf computes it (what std::abs(std::complex<float>) resolves to).
+__device__ __forceinline__ float cabs_ref(float x, float y)
+{
+    const double dx = (double)x, dy = (double)y;
+    return (float)sqrt(dx * dx + dy * dy);
+}
+
+}  // namespace
+
+// -----------------------------------------------------------------------------------------
+// k_det_ac: bit n of `mask` = ( |sum_{k<48} x[n-k-16] conj(x[n-k])| / sum_{k<64} |x[n-k]|^2 > 0.3 ).
+// The window sums are differences of workgroup-local prefix sums held in double: exact to float rounding,
+// where the reference's running float sums drift.  Reads 8 B per sample once, writes 1 bit per sample.
+// -----------------------------------------------------------------------------------------
+__global__ __launch_bounds__(AC_THREADS) void k_det_ac(const c32d *__restrict__ x, long long n, uint32_t *__restrict__ mask)
+{
+    __shared__ c32d s_x[AC_TILE + AC_HALO];
+    __shared__ double s_pr[AC_TILE + 64], s_pi[AC_TILE + 64], s_pp[AC_TILE + 64];
+    __shared__ double s_wr[AC_THREADS / 64][3];
+    const long long t0 = (long long)blockIdx.x * AC_TILE;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < AC_TILE + AC_HALO; i += AC_THREADS) s_x[i] = ld(x, t0 - AC_HALO + i, n);
+    __syncthreads();
+    // element e (0 .. AC_TILE+63) stands for sample t0 - 64 + e; each thread owns a run of consecutive elements
+    constexpr int NE = AC_TILE + 64;
+    constexpr int PER = (NE + AC_THREADS - 1) / AC_THREADS;  // 9
+    double ar[PER], ai[PER], ap[PER];
+    double sr = 0.0, si = 0.0, sp = 0.0;
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+        const int e = tid * PER + k;
+        double mr = 0.0, mi = 0.0, pw = 0.0;
+        if (e < NE) {
+            const c32d a = s_x[e + 16 - 16];  // x[n-16]: s_x index of sample t0-64+e is e+16
+            const c32d b = s_x[e + 16];
+            // multiply_conjugate_cc: a * conj(b)
+            mr = (double)(a.x * b.x + a.y * b.y);
+            mi = (double)(a.y * b.x - a.x * b.y);
+            pw = (double)(b.x * b.x + b.y * b.y);
+        }
+        sr += mr;
+        si += mi;
+        sp += pw;
+        ar[k] = sr;
+        ai[k] = si;
+        ap[k] = sp;
+    }
+    // exclusive scan of the thread totals: within the wave, then across the four waves
+    double xr = sr, xi = si, xp = sp;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const double ur = __shfl_up(xr, d), ui = __shfl_up(xi, d), up = __shfl_up(xp, d);
+        if (lane >= d) {
+            xr += ur;
+            xi += ui;
+            xp += up;
+        }
+    }
+    if (lane == 63) {
+        s_wr[wave][0] = xr;
+        s_wr[wave][1] = xi;
+        s_wr[wave][2] = xp;
+    }
+    __syncthreads();
+    double br = xr - sr, bi = xi - si, bp = xp - sp;
+    for (int w = 0; w < wave; w++) {
+        br += s_wr[w][0];
+        bi += s_wr[w][1];
+        bp += s_wr[w][2];
+    }
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+        const int e = tid * PER + k;
+        if (e < NE) {
+            s_pr[e] = br + ar[k];
+            s_pi[e] = bi + ai[k];
+            s_pp[e] = bp + ap[k];
+        }
+    }
+    __syncthreads();
+    // sample j of the tile is element e = j + 64; window sums over the last 48 / 64 elements
+    uint32_t bits = 0;
+#pragma unroll
+    for (int k = 0; k < AC_PER_THREAD; k++) {
+        const int j = tid * AC_PER_THREAD + k;
+        const int e = j + 64;
+        const float cr = (float)(s_pr[e] - s_pr[e - 48]);
+        const float ci = (float)(s_pi[e] - s_pi[e - 48]);
+        const float pw = (float)(s_pp[e] - s_pp[e - 64]);
+        const float ac = sqrtf(cr * cr + ci * ci) / pw;  // complex_to_mag, divide
+        if (t0 + j < n && ac > PLATEAU_AC) bits |= 1u << k;
+    }
+    // four neighbouring threads hold the 32 bits of one mask word
+    const uint32_t b1 = __shfl_down(bits, 1), b2 = __shfl_down(bits, 2), b3 = __shfl_down(bits, 3);
+    if ((tid & 3) == 0) {
+        const long long w = (t0 >> 5) + (tid >> 2);
+        if (w * 32 < n) mask[w] = bits | (b1 << 8) | (b2 << 16) | (b3 << 24);
+    }
+}
+
+// -----------------------------------------------------------------------------------------
+// Edges of the plateau bit stream.  Pass 0 counts the rising edges of each block of words, pass 1 writes the
+// rising and falling edge positions at the offsets an exclusive scan of the counts gave.
+// A run r is [rise[r], fall[r]); a run still open at the end of the capture falls at n.
+// -----------------------------------------------------------------------------------------
+constexpr int EDGE_WORDS = 1024;  // mask words per workgroup
+constexpr int EDGE_THREADS = 256;
+
+__device__ __forceinline__ void edge_words(const uint32_t *mask, long long nwords, long long w, uint32_t &rise, uint32_t &fall)
+{
+    const uint32_t cur = w < nwords ? mask[w] : 0u;
+    const uint32_t prev_top = (w > 0 && w - 1 < nwords) ? (mask[w - 1] >> 31) : 0u;
+    const uint32_t before = (cur << 1) | prev_top;  // bit k = sample 32w+k-1
+    rise = cur & ~before;
+    fall = ~cur & before;
+}
+
+__global__ __launch_bounds__(EDGE_THREADS) void k_det_edge_count(const uint32_t *__restrict__ mask, long long nwords,
+                                                                 uint32_t *__restrict__ blk_rise, uint32_t *__restrict__ blk_fall)
+{
+    __shared__ uint32_t s_r[EDGE_THREADS / 64], s_f[EDGE_THREADS / 64];
+    const long long w0 = (long long)blockIdx.x * EDGE_WORDS;
+    uint32_t nr = 0, nf = 0;
+    for (int i = threadIdx.x; i < EDGE_WORDS; i += EDGE_THREADS) {
+        uint32_t r, f;
+        // one word past the end is looked at too: a run open at the end of the capture falls there
+        edge_words(mask, nwords, w0 + i, r, f);
+        if (w0 + i > nwords) r = f = 0;
+        nr += __popc(r);
+        nf += __popc(f);
+    }
+    for (int d = 32; d > 0; d >>= 1) {
+        nr += __shfl_down(nr, d);
+        nf += __shfl_down(nf, d);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        s_r[threadIdx.x >> 6] = nr;
+        s_f[threadIdx.x >> 6] = nf;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t a = 0, b = 0;
+        for (int w = 0; w < EDGE_THREADS / 64; w++) {
+            a += s_r[w];
+            b += s_f[w];
+        }
+        blk_rise[blockIdx.x] = a;
+        blk_fall[blockIdx.x] = b;
+    }
+}
+
+// Exclusive scan of up to a few hundred thousand block counts by one workgroup; totals[slot] = sum.
+__global__ __launch_bounds__(1024) void k_det_scan(uint32_t *__restrict__ a, uint32_t *__restrict__ b, int nblk,
+                                                   uint32_t *__restrict__ totals, int slot)
+{
+    __shared__ uint32_t s_a[1024], s_b[1024];
+    __shared__ uint32_t s_ca, s_cb;
+    if (threadIdx.x == 0) s_ca = s_cb = 0;
+    __syncthreads();
+    for (int base = 0; base < nblk; base += 1024) {
+        const int i = base + threadIdx.x;
+        const uint32_t va = i < nblk ? a[i] : 0u, vb = (b && i < nblk) ? b[i] : 0u;
+        s_a[threadIdx.x] = va;
+        s_b[threadIdx.x] = vb;
+        __syncthreads();
+        for (int d = 1; d < 1024; d <<= 1) {
+            const uint32_t ta = threadIdx.x >= d ? s_a[threadIdx.x - d] : 0u;
+            const uint32_t tb = threadIdx.x >= d ? s_b[threadIdx.x - d] : 0u;
+            __syncthreads();
+            s_a[threadIdx.x] += ta;
+            s_b[threadIdx.x] += tb;
+            __syncthreads();
+        }
+        if (i < nblk) {
+            a[i] = s_ca + s_a[threadIdx.x] - va;
+            if (b) b[i] = s_cb + s_b[threadIdx.x] - vb;
+        }
+        __syncthreads();
+        if (threadIdx.x == 1023) {
+            s_ca += s_a[1023];
+            s_cb += s_b[1023];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        totals[slot] = s_ca;
+        totals[slot + 1] = s_cb;
+    }
+}
+
+__global__ __launch_bounds__(EDGE_THREADS) void k_det_edge_emit(const uint32_t *__restrict__ mask, long long nwords, long long n,
+                                                                const uint32_t *__restrict__ blk_rise,
+                                                                const uint32_t *__restrict__ blk_fall, long long cap,
+                                                                long long *__restrict__ rise, long long *__restrict__ fall)
+{
+    // one wave per workgroup walks the block's words in order so that positions come out sorted
+    const int lane = threadIdx.x;
+    if (lane >= 64) return;
+    const long long w0 = (long long)blockIdx.x * EDGE_WORDS;
+    long long pr = blk_rise[blockIdx.x], pf = blk_fall[blockIdx.x];
+    for (int base = 0; base < EDGE_WORDS; base += 64) {
+        const long long w = w0 + base + lane;
+        uint32_t r, f;
+        edge_words(mask, nwords, w, r, f);
+        if (w > nwords) r = f = 0;
+        int cr = __popc(r), cf = __popc(f);
+        int xr = cr, xf = cf;
+        for (int d = 1; d < 64; d <<= 1) {
+            const int ur = __shfl_up(xr, d), uf = __shfl_up(xf, d);
+            if (lane >= d) {
+                xr += ur;
+                xf += uf;
+            }
+        }
+        long long or_ = pr + xr - cr, of = pf + xf - cf;
+        while (r) {
+            const int k = __ffs(r) - 1;
+            r &= r - 1;
+            if (or_ < cap) rise[or_] = w * 32 + k;
+            or_++;
+        }
+        while (f) {
+            const int k = __ffs(f) - 1;
+            f &= f - 1;
+            long long p = w * 32 + k;
+            if (p > n) p = n;
+            if (of < cap) fall[of] = p;
+            of++;
+        }
+        pr += __shfl(xr, 63);
+        pf += __shfl(xf, 63);
+    }
+}
+
+// -----------------------------------------------------------------------------------------
+// k_det_trigger: one thread per run; the thread of a run that nothing earlier can influence walks its chain.
+//   trigger (lib/trigger_impl.cc:78-107): in a run that starts at a, the countdown starts at the first sample
+//   i >= a+20 at which no countdown is running (a countdown started at s ends, and fires the trigger byte, at
+//   s+79; the check at that very sample still sees it running) -- once per run -- and fires even if the run
+//   ends earlier.
+//   sync (lib/sync_impl.cc:76-93,94-131): a trigger byte it scans makes it consume 111 items from there, emitted
+//   or not; trigger bytes inside those items are never seen; fewer than 240 items left = never processed.
+// Per run: seen_at[r] = trigger position sync acts on (-1: none), scan_lo[r] = first item sync scanned after
+// its previous trigger, prev_seen[r] = run of that previous trigger (-1: none).
+// -----------------------------------------------------------------------------------------
+__global__ void k_det_trigger(const long long *__restrict__ rise, const long long *__restrict__ fall, long long nruns,
+                              long long n, long long *__restrict__ seen_at, long long *__restrict__ scan_lo,
+                              long long *__restrict__ prev_seen)
+{
+    const long long r0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r0 >= nruns) return;
+    const bool head = r0 == 0 || rise[r0] + PLATEAU_LEN > fall[r0 - 1] + INDEPENDENT_GAP;
+    if (!head) return;
+    long long fire_prev = -(1ll << 60), last_seen = -(1ll << 60), last_seen_run = -1;
+    for (long long r = r0; r < nruns; r++) {
+        const long long a = rise[r], e = fall[r];
+        if (r > r0 && a + PLATEAU_LEN > fall[r - 1] + INDEPENDENT_GAP) break;  // next chain
+        long long t = -1;
+        if (e - a > PLATEAU_LEN) {
+            long long s = a + PLATEAU_LEN;
+            if (fire_prev + 1 > s) s = fire_prev + 1;
+            if (s <= e - 1) {
+                t = s + COUNT_DOWN - 1;
+                fire_prev = t;
+            }
+        }
+        long long seen = -1;
+        if (t >= 0 && t < n && t >= last_seen + SYNC_RES && n - t >= SYNC_BUF) seen = t;
+        seen_at[r] = seen;
+        scan_lo[r] = last_seen < 0 ? 0 : last_seen + SYNC_RES;
+        prev_seen[r] = last_seen_run;
+        if (seen >= 0) {
+            last_seen = seen;
+            last_seen_run = r;
+        }
+    }
+}
+
+// -----------------------------------------------------------------------------------------
+// k_det_sync: one thread per run whose trigger sync acts on.
+// -----------------------------------------------------------------------------------------
+namespace {
+
+// presiso's two window sums at sample i, from scratch (double accumulation, float products as the blocks make them)
+__device__ void window_sums(const c32d *x, long long n, long long i, double &cr, double &ci, double &pw)
+{
+    cr = ci = pw = 0.0;
+    for (int k = 0; k < 64; k++) {
+        const c32d b = ld(x, i - k, n);
+        pw += (double)(b.x * b.x + b.y * b.y);
+        if (k < 48) {
+            const c32d a = ld(x, i - k - 16, n);
+            cr += (double)(a.x * b.x + a.y * b.y);
+            ci += (double)(a.y * b.x - a.x * b.y);
+        }
+    }
+}
+
+// Position of the last "new maximum" flag (trigger bit 1, lib/trigger_impl.cc:81-86) in [lo, hi) of the run that
+// starts at a: the first position of the maximum of ac over [a, hi), provided it is >= lo; -1 otherwise.
+__device__ long long last_max_flag(const c32d *x, long long n, long long a, long long hi, long long lo, float &vr, float &vi)
+{
+    double cr, ci, pw;
+    window_sums(x, n, a, cr, ci, pw);
+    float best = 0.0f;
+    long long at = -1;
+    for (long long i = a; i < hi; i++) {
+        if (i > a) {
+            const c32d b = ld(x, i, n), a16 = ld(x, i - 16, n);
+            const c32d ob = ld(x, i - 48, n), oa = ld(x, i - 64, n);
+            cr += (double)(a16.x * b.x + a16.y * b.y) - (double)(oa.x * ob.x + oa.y * ob.y);
+            ci += (double)(a16.y * b.x - a16.x * b.y) - (double)(oa.y * ob.x - oa.x * ob.y);
+            pw += (double)(b.x * b.x + b.y * b.y) - (double)(oa.x * oa.x + oa.y * oa.y);
+        }
+        const float fr = (float)cr, fi = (float)ci;
+        const float ac = sqrtf(fr * fr + fi * fi) / (float)pw;
+        if (ac > best) {
+            best = ac;
+            at = i;
+            vr = fr;
+            vi = fi;
+        }
+    }
+    return at >= lo ? at : -1;
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(64) void k_det_sync(const c32d *__restrict__ x, long long n, const long long *__restrict__ rise,
+                                                 const long long *__restrict__ fall, long long nruns,
+                                                 const long long *__restrict__ seen_at, const long long *__restrict__ scan_lo,
+                                                 const long long *__restrict__ prev_seen, long long *__restrict__ out_pos,
+                                                 float *__restrict__ out_rad, float *__restrict__ out_snr,
+                                                 float *__restrict__ out_rssi, uint32_t *__restrict__ emitted)
+{
+    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nruns) return;
+    emitted[r] = 0;
+    const long long T = seen_at[r];
+    if (T < 0) return;
+
+    // ---- L-LTF autocorrelation over 111 positions, running sums exactly as lib/sync_impl.cc:139-171
+    const c32d *sig = x + T;
+    float msr = 0.0f, msi = 0.0f, s1 = 0.0f, s2 = 0.0f;
+    for (int i = 0; i < 64; i++) {
+        const c32d a = sig[i], b = sig[i + 64];
+        msr += a.x * b.x + a.y * b.y;  // a * conj(b): (ac+bd, bc-ad)
+        msi += a.y * b.x - a.x * b.y;
+        const float ma = cabs_ref(a.x, a.y), mb = cabs_ref(b.x, b.y);
+        s1 += ma * ma;
+        s2 += mb * mb;
+    }
+    float best = -1.0f, best_pwr = 0.0f;
+    int mx = 0;
+    // first pass: maximum (first occurrence); the values are recomputed in the shoulder search
+    {
+        float r_ = msr, i_ = msi, p1 = s1, p2 = s2;
+        for (int i = 0; i < SYNC_RES; i++) {
+            const float ac = cabs_ref(r_, i_) / sqrtf(p1) / sqrtf(p2);
+            if (i == 0 || ac > best) {
+                best = ac;
+                best_pwr = p1;
+                mx = i;
+            }
+            const c32d a = sig[i], b = sig[i + 64], c = sig[i + 128];
+            r_ -= a.x * b.x + a.y * b.y;
+            i_ -= a.y * b.x - a.x * b.y;
+            const float ma = cabs_ref(a.x, a.y), mb = cabs_ref(b.x, b.y), mc = cabs_ref(c.x, c.y);
+            p1 -= ma * ma;
+            p2 -= mb * mb;
+            r_ += b.x * c.x + b.y * c.y;
+            i_ += b.y * c.x - b.x * c.y;
+            p1 += mb * mb;
+            p2 += mc * mc;
+        }
+    }
+    if (!((double)best > 0.5)) return;  // lib/sync_impl.cc:99
+    const float lim = (float)((double)best * 0.8);
+    int l = mx, rr = mx;
+    {
+        // second pass: l = last index <= mx below the limit, rr = first index >= mx below it
+        float r_ = msr, i_ = msi, p1 = s1, p2 = s2;
+        bool have_r = false;
+        for (int i = 0; i < SYNC_RES; i++) {
+            const float ac = cabs_ref(r_, i_) / sqrtf(p1) / sqrtf(p2);
+            if (i <= mx && ac < lim) l = i;
+            if (i >= mx && !have_r && ac < lim) {
+                rr = i;
+                have_r = true;
+            }
+            const c32d a = sig[i], b = sig[i + 64], c = sig[i + 128];
+            r_ -= a.x * b.x + a.y * b.y;
+            i_ -= a.y * b.x - a.x * b.y;
+            const float ma = cabs_ref(a.x, a.y), mb = cabs_ref(b.x, b.y), mc = cabs_ref(c.x, c.y);
+            p1 -= ma * ma;
+            p2 -= mb * mb;
+            r_ += b.x * c.x + b.y * c.y;
+            i_ += b.y * c.x - b.x * c.y;
+            p1 += mb * mb;
+            p2 += mc * mc;
+        }
+    }
+    const int m = (l + rr) / 2;
+
+    // ---- the conjugate average sync holds when it meets this trigger byte (lib/sync_impl.cc:85-88): the value at
+    // the last "new maximum" flag it scanned.  Flags inside the 111 items it skipped after an earlier trigger were
+    // never seen; then the value found for that earlier trigger is still in place.
+    float cvr = 0.0f, cvi = 0.0f;
+    {
+        long long run = r;
+        for (int guard = 0; guard < 64 && run >= 0; guard++) {
+            const long long t = seen_at[run], lo = scan_lo[run];
+            // the latest run that starts before the trigger byte holds the last flag before it; if that flag lies
+            // in skipped items so does every earlier one
+            long long q = run;
+            while (q + 1 < nruns && rise[q + 1] < t) q++;
+            const long long hi = fall[q] < t ? fall[q] : t;
+            if (last_max_flag(x, n, rise[q], hi, lo, cvr, cvi) >= 0) break;
+            cvr = cvi = 0.0f;
+            run = prev_seen[run];
+        }
+    }
+
+    // ---- CFO: coarse from the 16-lag average, fine from the two LTF halves (lib/sync_impl.cc:173-191)
+    const float step_stf = atan2f(cvi, cvr) / 16.0f;
+    const c32d *ls = x + T + m;
+    float csr = 0.0f, csi = 0.0f;
+    for (int i = 0; i < 64; i++) {
+        const c32d a = ls[i], b = ls[i + 64];
+        const float ca = cosf(i * step_stf), sa = sinf(i * step_stf);
+        const float cb = cosf((i + 64) * step_stf), sb = sinf((i + 64) * step_stf);
+        const float ar = a.x * ca - a.y * sa, ai = a.x * sa + a.y * ca;
+        const float br = b.x * cb - b.y * sb, bi = b.x * sb + b.y * cb;
+        csr += ar * br + ai * bi;
+        csi += ai * br - ar * bi;
+    }
+    const float step_ltf = atan2f(csi / 64.0f, csr / 64.0f) / 64.0f;
+    const double mxd = (double)best;
+    out_pos[r] = T + m;
+    out_rad[r] = step_stf + step_ltf;
+    out_snr[r] = (float)(10.0 * log10(mxd / (1.0 - mxd)));
+    out_rssi[r] = best_pwr / 64.0f;
+    emitted[r] = 1;
+}
+
+// -----------------------------------------------------------------------------------------
+// k_det_emit: the emitted sync bytes, in stream order, as frame descriptors.
+// -----------------------------------------------------------------------------------------
+__global__ void k_det_flag_count(const uint32_t *__restrict__ emitted, long long nruns, uint32_t *__restrict__ blk)
+{
+    __shared__ uint32_t s[4];
+    const long long r = (long long)blockIdx.x * 256 + threadIdx.x;
+    uint32_t v = r < nruns ? emitted[r] : 0u;
+    for (int d = 32; d > 0; d >>= 1) v += __shfl_down(v, d);
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) blk[blockIdx.x] = s[0] + s[1] + s[2] + s[3];
+}
+
+__global__ void k_det_emit(const uint32_t *__restrict__ emitted, long long nruns, const uint32_t *__restrict__ blk,
+                           const long long *__restrict__ pos, const float *__restrict__ rad, const float *__restrict__ snr,
+                           const float *__restrict__ rssi, long long n, gr80211_frame_desc *__restrict__ desc, int max_desc)
+{
+    __shared__ uint32_t s[256];
+    const long long r = (long long)blockIdx.x * 256 + threadIdx.x;
+    const uint32_t v = r < nruns ? emitted[r] : 0u;
+    s[threadIdx.x] = v;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {
+        const uint32_t t = threadIdx.x >= (unsigned)d ? s[threadIdx.x - d] : 0u;
+        __syncthreads();
+        s[threadIdx.x] += t;
+        __syncthreads();
+    }
+    if (!v) return;
+    const long long o = (long long)blk[blockIdx.x] + s[threadIdx.x] - 1;
+    if (o >= max_desc) return;
+    gr80211_frame_desc d;
+    d.sync_off = (uint64_t)pos[r];
+    const long long left = n - pos[r];
+    d.n_avail = left > 0xffffffffll ? 0xffffffffu : (uint32_t)left;
+    d.rad = rad[r];
+    d.snr = snr[r];
+    d.rssi = rssi[r];
+    d.reserved[0] = d.reserved[1] = 0;
+    desc[o] = d;
+}
+
+// -----------------------------------------------------------------------------------------
+// launchers
+// -----------------------------------------------------------------------------------------
+long long det_mask_words(long long n) { return (n + 31) / 32 + 1; }
+int det_edge_blocks(long long n) { return (int)((det_mask_words(n) + EDGE_WORDS) / EDGE_WORDS); }
+
+void launch_det_ac(const void *iq, long long n, uint32_t *mask, hipStream_t s)
+{
+    const int nblk = (int)((n + AC_TILE - 1) / AC_TILE);
+    hipLaunchKernelGGL(k_det_ac, dim3(nblk), dim3(AC_THREADS), 0, s, (const c32d *)iq, n, mask);
+}
+
+void launch_det_edge_count(const uint32_t *mask, long long n, uint32_t *blk_rise, uint32_t *blk_fall, uint32_t *totals,
+                           hipStream_t s)
+{
+    const long long nwords = (n + 31) / 32;
+    const int nblk = det_edge_blocks(n);
+    hipLaunchKernelGGL(k_det_edge_count, dim3(nblk), dim3(EDGE_THREADS), 0, s, mask, nwords, blk_rise, blk_fall);
+    hipLaunchKernelGGL(k_det_scan, dim3(1), dim3(1024), 0, s, blk_rise, blk_fall, nblk, totals, 0);
+}
+
+void launch_det_edge_emit(const uint32_t *mask, long long n, const uint32_t *blk_rise, const uint32_t *blk_fall,
+                          long long cap, long long *rise, long long *fall, hipStream_t s)
+{
+    const long long nwords = (n + 31) / 32;
+    hipLaunchKernelGGL(k_det_edge_emit, dim3(det_edge_blocks(n)), dim3(64), 0, s, mask, nwords, n, blk_rise, blk_fall,
+                       cap, rise, fall);
+}
+
+void launch_det_trigger_sync(const void *iq, long long n, const long long *rise, const long long *fall, long long nruns,
+                             long long *seen_at, long long *scan_lo, long long *prev_seen, long long *pos, float *rad,
+                             float *snr, float *rssi, uint32_t *emitted, uint32_t *blk, uint32_t *totals, hipStream_t s)
+{
+    if (nruns <= 0) return;
+    const int nb = (int)((nruns + 255) / 256);
+    // a run that is not the head of a chain gets its entries from the head's walk; clear first for runs that
+    // no walk reaches (none by construction, but the arrays are reused between calls)
+    hipLaunchKernelGGL(k_det_trigger, dim3(nb), dim3(256), 0, s, rise, fall, nruns, n, seen_at, scan_lo, prev_seen);
+    hipLaunchKernelGGL(k_det_sync, dim3((unsigned)((nruns + 63) / 64)), dim3(64), 0, s, (const c32d *)iq, n, rise, fall,
+                       nruns, seen_at, scan_lo, prev_seen, pos, rad, snr, rssi, emitted);
+    hipLaunchKernelGGL(k_det_flag_count, dim3(nb), dim3(256), 0, s, emitted, nruns, blk);
+    hipLaunchKernelGGL(k_det_scan, dim3(1), dim3(1024), 0, s, blk, (uint32_t *)nullptr, nb, totals, 2);
+}
+
+void launch_det_emit(const uint32_t *emitted, long long nruns, const uint32_t *blk, const long long *pos, const float *rad,
+                     const float *snr, const float *rssi, long long n, gr80211_frame_desc *desc, int max_desc, hipStream_t s)
+{
+    if (nruns <= 0) return;
+    const int nb = (int)((nruns + 255) / 256);
+    hipLaunchKernelGGL(k_det_emit, dim3(nb), dim3(256), 0, s, emitted, nruns, blk, pos, rad, snr, rssi, n, desc, max_desc);
+}
+
+}  // namespace gr80211

@@ -5,6 +5,7 @@
 #include <mutex>
 #include <string>
 
+#include "detect_kernels.h"
 #include "rx_kernels.h"
 
 using namespace gr80211;
@@ -24,6 +25,9 @@ struct gr80211_ctx {
     std::string err;
     // workspaces (grown on demand, never shrunk)
     Buf desc, ddesc, info, chan1, chan2, llr, slot_frame, groups, dec, bitsw, totals_d, sched_ws, blk_llr;
+    // frame detection
+    Buf det_mask, det_blk, det_runs, det_rec, det_totals_d;
+    uint32_t *det_totals_h = nullptr;  // pinned
     SchedTotals *totals_h = nullptr;  // pinned
     bool profiling = false;
     bool split_decode = false;  // GR80211_SPLIT_DECODE=1: forward pass and traceback as two kernels
@@ -243,6 +247,10 @@ int gr80211_create(gr80211_ctx **out, int device)
         delete c;
         return GR80211_ERR_NOMEM;
     }
+    if (hipHostMalloc((void **)&c->det_totals_h, 4 * sizeof(uint32_t)) != hipSuccess) {
+        gr80211_destroy(c);
+        return GR80211_ERR_NOMEM;
+    }
     for (auto &e : c->ev)
         if (hipEventCreate(&e) != hipSuccess) {
             gr80211_destroy(c);
@@ -258,9 +266,11 @@ void gr80211_destroy(gr80211_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (Buf *b : {&c->desc, &c->ddesc, &c->info, &c->chan1, &c->chan2, &c->llr, &c->slot_frame, &c->groups, &c->dec,
-                   &c->bitsw, &c->totals_d, &c->sched_ws, &c->blk_llr})
+                   &c->bitsw, &c->totals_d, &c->sched_ws, &c->blk_llr, &c->det_mask, &c->det_blk, &c->det_runs,
+                   &c->det_rec, &c->det_totals_d})
         release(*b);
     if (c->totals_h) (void)hipHostFree(c->totals_h);
+    if (c->det_totals_h) (void)hipHostFree(c->det_totals_h);
     for (auto &e : c->ev)
         if (e) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -297,6 +307,52 @@ int gr80211_rx_batch(gr80211_ctx *c, const void *d_iq0, const void *d_iq1, uint6
     if (d_info)
         HIP_TRY(c, hipMemcpyAsync(d_info, c->info.p, (size_t)n * sizeof(gr80211_frame_info), hipMemcpyDeviceToDevice, s));
     return finish_timing(c, s);
+}
+
+int gr80211_detect(gr80211_ctx *c, const void *d_iq, uint64_t n_samples, gr80211_frame_desc *d_desc, int max_desc,
+                   int *n_desc, void *stream)
+{
+    if (!c) return GR80211_ERR_ARG;
+    if (!n_desc) return fail(c, GR80211_ERR_ARG, "gr80211_detect: bad argument");
+    *n_desc = 0;
+    if (n_samples == 0) return GR80211_OK;
+    if (!d_iq || !d_desc || max_desc < 0 || n_samples > (1ull << 40))
+        return fail(c, GR80211_ERR_ARG, "gr80211_detect: bad argument");
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = pick(c, stream);
+    const long long n = (long long)n_samples;
+    int rc;
+    const int eb = det_edge_blocks(n);
+    if ((rc = ensure(c, c->det_mask, (size_t)det_mask_words(n) * 4))) return rc;
+    if ((rc = ensure(c, c->det_blk, (size_t)eb * 2 * 4 + 64))) return rc;
+    if ((rc = ensure(c, c->det_totals_d, 4 * 4))) return rc;
+    uint32_t *mask = (uint32_t *)c->det_mask.p;
+    uint32_t *blk_r = (uint32_t *)c->det_blk.p, *blk_f = blk_r + eb;
+    uint32_t *tot_d = (uint32_t *)c->det_totals_d.p;
+    launch_det_ac(d_iq, n, mask, s);
+    launch_det_edge_count(mask, n, blk_r, blk_f, tot_d, s);
+    HIP_TRY(c, hipMemcpyAsync(c->det_totals_h, tot_d, 2 * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    const long long nruns = c->det_totals_h[0];
+    if (c->det_totals_h[1] != c->det_totals_h[0]) return fail(c, GR80211_ERR_HIP, "gr80211_detect: edge lists disagree");
+    if (nruns == 0) return GR80211_OK;
+    // per run: rise, fall, seen_at, scan_lo, prev_seen, pos (8 B each); rad, snr, rssi, emitted (4 B each)
+    if ((rc = ensure(c, c->det_runs, (size_t)nruns * 6 * 8))) return rc;
+    if ((rc = ensure(c, c->det_rec, (size_t)nruns * 4 * 4 + (size_t)(nruns / 256 + 2) * 4))) return rc;
+    long long *rise = (long long *)c->det_runs.p, *fall = rise + nruns, *seen_at = fall + nruns,
+              *scan_lo = seen_at + nruns, *prev_seen = scan_lo + nruns, *pos = prev_seen + nruns;
+    float *rad = (float *)c->det_rec.p, *snr = rad + nruns, *rssi = snr + nruns;
+    uint32_t *emitted = (uint32_t *)(rssi + nruns), *blk2 = emitted + nruns;
+    launch_det_edge_emit(mask, n, blk_r, blk_f, nruns, rise, fall, s);
+    launch_det_trigger_sync(d_iq, n, rise, fall, nruns, seen_at, scan_lo, prev_seen, pos, rad, snr, rssi, emitted, blk2,
+                            tot_d, s);
+    launch_det_emit(emitted, nruns, blk2, pos, rad, snr, rssi, n, d_desc, max_desc, s);
+    HIP_TRY(c, hipMemcpyAsync(c->det_totals_h + 2, tot_d + 2, 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    HIP_TRY(c, hipGetLastError());
+    *n_desc = (int)c->det_totals_h[2];
+    if (*n_desc > max_desc) return fail(c, GR80211_ERR_ARG, "gr80211_detect: more sync points than max_desc");
+    return GR80211_OK;
 }
 
 int gr80211_signal_batch(gr80211_ctx *c, const void *d_iq0, const void *d_iq1, uint64_t arena_len,

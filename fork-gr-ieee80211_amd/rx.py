@@ -53,7 +53,7 @@ assert FRAME_INFO_DTYPE.itemsize == C.sizeof(FrameInfo) == 112
 assert DEC_DESC_DTYPE.itemsize == C.sizeof(DecDesc) == 40
 
 EXPORTS = [
-    "gr80211_create", "gr80211_destroy", "gr80211_last_error", "gr80211_sync", "gr80211_rx_batch", "gr80211_signal_batch",
+    "gr80211_create", "gr80211_destroy", "gr80211_last_error", "gr80211_sync", "gr80211_rx_batch", "gr80211_signal_batch", "gr80211_detect",
     "gr80211_demod_batch", "gr80211_decode_batch", "gr80211_dev_alloc", "gr80211_dev_free",
     "gr80211_copy_h2d", "gr80211_copy_d2h", "gr80211_set_profiling", "gr80211_last_timing",
     "gr80211_version", "gr80211_table_checksum",
@@ -78,6 +78,7 @@ def load_library():
     L.gr80211_last_error.restype = C.c_char_p
     L.gr80211_sync.argtypes = [vp, vp]
     L.gr80211_rx_batch.argtypes = [vp, vp, vp, C.c_uint64, vp, C.c_int, C.c_uint, vp, C.c_int, vp, vp, vp, vp]
+    L.gr80211_detect.argtypes = [vp, vp, C.c_uint64, vp, C.c_int, C.POINTER(C.c_int), vp]
     L.gr80211_signal_batch.argtypes = [vp, vp, vp, C.c_uint64, vp, C.c_int, C.c_uint, vp, vp]
     L.gr80211_demod_batch.argtypes = [vp, vp, vp, C.c_uint64, vp, C.c_int, C.c_uint, vp, C.POINTER(vp),
                                       C.POINTER(C.c_uint64), vp]
@@ -217,6 +218,20 @@ class RxContext:
             C.c_void_p(info.data_ptr()) if info is not None else None, self._stream())
         self._check(rc, "gr80211_rx_batch")
         return keep
+
+    def detect(self, iq, max_desc=None):
+        """Frame detection over a capture (complex64 CUDA tensor).  Returns (desc tensor on the device as
+        bytes, n) -- desc[: n * 32] feeds rx_batch / signal_batch directly."""
+        t = self.torch
+        assert iq.is_cuda and iq.dtype == t.complex64 and iq.is_contiguous()
+        if max_desc is None:
+            max_desc = iq.numel() // 320 + 16
+        desc = t.zeros(max(max_desc, 1) * FRAME_DESC_DTYPE.itemsize, dtype=t.uint8, device=self.dev)
+        n = C.c_int(0)
+        rc = self.lib.gr80211_detect(self.h, C.c_void_p(iq.data_ptr()), iq.numel(), C.c_void_p(desc.data_ptr()),
+                                     max_desc, C.byref(n), self._stream())
+        self._check(rc, "gr80211_detect")
+        return desc, n.value
 
     def signal_batch(self, iq0, iq1, desc, n_frames):
         """IQ -> per-frame tag records only (L-SIG, format detection, SIG fields).  Returns the info ndarray."""

@@ -118,6 +118,18 @@ int gr80211_rx_batch(gr80211_ctx *ctx, const void *d_iq0, const void *d_iq1, uin
                      gr80211_frame_info *d_info, void *stream);
 
 /*
+ * Frame detection over a whole capture: the work of the blocks upstream of `signal` in the reference's receive
+ * flowgraph (examples/rx.grc: presiso -> trigger -> sync; examples/presiso.grc:68-137,218-229,
+ * lib/trigger_impl.cc:59-117, lib/sync_impl.cc:61-196).  d_iq: complex64 samples of the (first) antenna.
+ * Writes one descriptor per sync byte `sync` would emit, in stream order: sync_off = its position
+ * (L-LTF start + 16), rad/snr/rssi = its tags, n_avail = samples from there to the end of the capture.  The
+ * descriptors are ready for gr80211_signal_batch / gr80211_rx_batch with GR80211_FLAG_DESC_ON_DEVICE.
+ * *n_desc (host) = number of sync bytes; more than max_desc is an error (the first max_desc are written).
+ */
+int gr80211_detect(gr80211_ctx *ctx, const void *d_iq, uint64_t n_samples, gr80211_frame_desc *d_desc, int max_desc,
+                   int *n_desc, void *stream);
+
+/*
  * signal/signal2 (and the format detection of demod/demod2) only: L-SIG decode, format detection,
  * HT-SIG / VHT-SIG-A / VHT-SIG-B decode and channel estimation of every frame, no data symbols.
  * d_info[i] receives status, L-SIG mcs/len, nsamp (the number of samples `signal` forwards after

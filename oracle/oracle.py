@@ -37,8 +37,8 @@ class Frame(C.Structure):
 
 def build(force=False):
     so = os.path.join(_HERE, "liboracle.so")
-    src = os.path.join(_HERE, "rx_oracle.c")
-    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("rx_oracle.c", "detect_oracle.c", "rx_oracle.h")]
+    if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return so
 
@@ -160,4 +160,40 @@ def rx_frame(iq0, iq1, sync_idx, rad=0.0, want_llr=True):
     res = dict(status=st, frame=f, n_pdu=npdu.value, blob=blob, pdus=split_pdus(blob))
     if want_llr and st == 0:
         res["llr"] = llr[: f.total].copy()
+    return res
+
+
+def detect(iq, cap=None, want_stages=False):
+    """presiso -> trigger -> sync over one capture (oracle/detect_oracle.c).
+    Returns dict(pos, rad, snr, rssi[, ac, conj, trig, trig_idx, conj_idx])."""
+    L = lib()
+    iq = np.ascontiguousarray(iq, dtype=np.complex64)
+    n = len(iq)
+    cap = cap or max(16, n // 400 + 16)
+    ac = np.zeros(n, np.float32)
+    conj = np.zeros(n, np.complex64)
+    trig = np.zeros(n, np.uint8)
+    pos = np.zeros(cap, np.int64)
+    tidx = np.zeros(cap, np.int64)
+    cidx = np.zeros(cap, np.int64)
+    rad = np.zeros(cap, np.float32)
+    snr = np.zeros(cap, np.float32)
+    rssi = np.zeros(cap, np.float32)
+    lp = C.POINTER(C.c_long)
+    L.orc_presiso.argtypes = [C.POINTER(C.c_float), C.c_long, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.orc_presiso.restype = None
+    L.orc_trigger.argtypes = [C.POINTER(C.c_float), C.c_long, C.POINTER(C.c_uint8)]
+    L.orc_trigger.restype = None
+    L.orc_sync.argtypes = [C.POINTER(C.c_uint8), C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_long, lp,
+                           C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), lp, lp, C.c_long]
+    L.orc_sync.restype = C.c_long
+    L.orc_presiso(_fp(iq.view(np.float32)), n, _fp(ac), _fp(conj.view(np.float32)))
+    L.orc_trigger(_fp(ac), n, _u8(trig))
+    cnt = L.orc_sync(_u8(trig), _fp(conj.view(np.float32)), _fp(iq.view(np.float32)), n,
+                     pos.ctypes.data_as(lp), _fp(rad), _fp(snr), _fp(rssi), tidx.ctypes.data_as(lp),
+                     cidx.ctypes.data_as(lp), cap)
+    assert cnt <= cap, "raise cap"
+    res = dict(pos=pos[:cnt].copy(), rad=rad[:cnt].copy(), snr=snr[:cnt].copy(), rssi=rssi[:cnt].copy())
+    if want_stages:
+        res.update(ac=ac, conj=conj, trig=trig, trig_idx=tidx[:cnt].copy(), conj_idx=cidx[:cnt].copy())
     return res
