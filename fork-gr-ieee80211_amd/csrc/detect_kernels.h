@@ -24,4 +24,10 @@ void launch_det_trigger_sync(const void *iq, long long n, const long long *rise,
 void launch_det_emit(const uint32_t *emitted, long long nruns, const uint32_t *blk, const long long *pos, const float *rad,
                      const float *snr, const float *rssi, long long n, gr80211_frame_desc *desc, int max_desc, hipStream_t s);
 
+// `signal`'s trigger search over nd sync bytes whose L-SIG results are in info: out[0 .. *count) = the bytes it deals
+// with, in order, n_avail cut to the frame's own samples.  jump_a, jump_b, path: nd + 1 entries each.
+void launch_span_filter(const gr80211_frame_desc *desc, const gr80211_frame_info *info, int nd, long long n,
+                        int32_t *jump_a, int32_t *jump_b, int32_t *path, gr80211_frame_desc *out, uint32_t *count,
+                        hipStream_t s);
+
 }  // namespace gr80211

@@ -536,6 +536,74 @@ __global__ void k_det_emit(const uint32_t *__restrict__ emitted, long long nruns
 }
 
 // -----------------------------------------------------------------------------------------
+// The trigger search of `signal` over the sync bytes of a capture (lib/signal_impl.cc:75-106,153-202): a sync
+// byte starts a frame; while the frame's 224 + nsamp samples pass (80 after a failed L-SIG check) later sync
+// bytes are not looked at.  Sequential in the reference; here next[i] = the first sync byte `signal` looks at
+// after it dealt with byte i, and the bytes it deals with are the path 0, next[0], next[next[0]], ... found by
+// pointer doubling.  Byte index nd stands for "end of capture".
+// -----------------------------------------------------------------------------------------
+__global__ void k_span_next(const gr80211_frame_desc *__restrict__ desc, const gr80211_frame_info *__restrict__ info, int nd,
+                            long long n, int32_t *__restrict__ next)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > nd) return;
+    if (i == nd) {
+        next[i] = nd;
+        return;
+    }
+    const long long pos = (long long)desc[i].sync_off;
+    if (n - pos < 224) {  // `signal` waits for 224 samples that never come
+        next[i] = nd;
+        return;
+    }
+    const gr80211_frame_info fi = info[i];
+    const long long lim = pos + (fi.status == GR80211_ST_DROP_LSIG ? 80 : 224 + (fi.nsamp > 0 ? fi.nsamp : 0));
+    int lo = i + 1, hi = nd;  // first j in (i, nd] with sync_off >= lim
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if ((long long)desc[mid].sync_off >= lim) hi = mid;
+        else lo = mid + 1;
+    }
+    next[i] = lo;
+}
+
+// path[m + half] = jump[path[m]] for m < half; then jump = jump o jump
+__global__ void k_span_extend(const int32_t *__restrict__ jump, int32_t *__restrict__ path, int half, int cap)
+{
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m < half && m + half < cap) path[m + half] = jump[path[m]];
+}
+__global__ void k_span_square(const int32_t *__restrict__ jump, int32_t *__restrict__ jump2, int nd)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i <= nd) jump2[i] = jump[jump[i]];
+}
+__global__ void k_span_init(int32_t *__restrict__ path, uint32_t *__restrict__ count)
+{
+    path[0] = 0;
+    *count = 0;
+}
+
+// The bytes on the path become the descriptors of the RX batch; a frame sees its own samples only.
+__global__ void k_span_gather(const int32_t *__restrict__ path, int cap, int nd, const gr80211_frame_desc *__restrict__ desc,
+                              const gr80211_frame_info *__restrict__ info, long long n,
+                              gr80211_frame_desc *__restrict__ out, uint32_t *__restrict__ count)
+{
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= cap) return;
+    const int i = path[m];
+    if (i >= nd) return;
+    gr80211_frame_desc d = desc[i];
+    const gr80211_frame_info fi = info[i];
+    const long long left = n - (long long)d.sync_off;
+    long long span = 224 + (long long)(fi.nsamp > 0 ? fi.nsamp : 0);
+    if (span > left) span = left;
+    d.n_avail = (uint32_t)span;
+    out[m] = d;
+    atomicAdd(count, 1u);
+}
+
+// -----------------------------------------------------------------------------------------
 // launchers
 // -----------------------------------------------------------------------------------------
 long long det_mask_words(long long n) { return (n + 31) / 32 + 1; }
@@ -585,6 +653,26 @@ void launch_det_emit(const uint32_t *emitted, long long nruns, const uint32_t *b
     if (nruns <= 0) return;
     const int nb = (int)((nruns + 255) / 256);
     hipLaunchKernelGGL(k_det_emit, dim3(nb), dim3(256), 0, s, emitted, nruns, blk, pos, rad, snr, rssi, n, desc, max_desc);
+}
+
+// path (capacity nd + 1 entries) and two jump buffers of nd + 1 entries; *count = bytes on the path.
+void launch_span_filter(const gr80211_frame_desc *desc, const gr80211_frame_info *info, int nd, long long n,
+                        int32_t *jump_a, int32_t *jump_b, int32_t *path, gr80211_frame_desc *out, uint32_t *count,
+                        hipStream_t s)
+{
+    const int nb = (nd + 1 + 255) / 256;
+    hipLaunchKernelGGL(k_span_next, dim3(nb), dim3(256), 0, s, desc, info, nd, n, jump_a);
+    hipLaunchKernelGGL(k_span_init, dim3(1), dim3(1), 0, s, path, count);
+    int32_t *ja = jump_a, *jb = jump_b;
+    const int cap = nd + 1;
+    for (int half = 1; half < cap; half <<= 1) {
+        hipLaunchKernelGGL(k_span_extend, dim3((half + 255) / 256), dim3(256), 0, s, ja, path, half, cap);
+        hipLaunchKernelGGL(k_span_square, dim3(nb), dim3(256), 0, s, ja, jb, nd);
+        int32_t *t = ja;
+        ja = jb;
+        jb = t;
+    }
+    hipLaunchKernelGGL(k_span_gather, dim3((cap + 255) / 256), dim3(256), 0, s, path, cap, nd, desc, info, n, out, count);
 }
 
 }  // namespace gr80211

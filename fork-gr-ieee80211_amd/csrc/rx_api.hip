@@ -26,7 +26,7 @@ struct gr80211_ctx {
     // workspaces (grown on demand, never shrunk)
     Buf desc, ddesc, info, chan1, chan2, llr, slot_frame, groups, dec, bitsw, totals_d, sched_ws, blk_llr;
     // frame detection
-    Buf det_mask, det_blk, det_runs, det_rec, det_totals_d;
+    Buf det_mask, det_blk, det_runs, det_rec, det_totals_d, cap_desc, cap_ws;
     uint32_t *det_totals_h = nullptr;  // pinned
     SchedTotals *totals_h = nullptr;  // pinned
     bool profiling = false;
@@ -209,6 +209,53 @@ int front_end(gr80211_ctx *c, hipStream_t s, const void *d_iq0, const void *d_iq
     return GR80211_OK;
 }
 
+// Detection up to the per-run records (left in the context's workspaces).  *n_emit = sync bytes emitted.
+int detect_core(gr80211_ctx *c, hipStream_t s, const void *d_iq, long long n, long long *nruns_out, int *n_emit)
+{
+    *nruns_out = 0;
+    *n_emit = 0;
+    int rc;
+    const int eb = det_edge_blocks(n);
+    if ((rc = ensure(c, c->det_mask, (size_t)det_mask_words(n) * 4))) return rc;
+    if ((rc = ensure(c, c->det_blk, (size_t)eb * 2 * 4 + 64))) return rc;
+    if ((rc = ensure(c, c->det_totals_d, 4 * 4))) return rc;
+    uint32_t *mask = (uint32_t *)c->det_mask.p;
+    uint32_t *blk_r = (uint32_t *)c->det_blk.p, *blk_f = blk_r + eb;
+    uint32_t *tot_d = (uint32_t *)c->det_totals_d.p;
+    launch_det_ac(d_iq, n, mask, s);
+    launch_det_edge_count(mask, n, blk_r, blk_f, tot_d, s);
+    HIP_TRY(c, hipMemcpyAsync(c->det_totals_h, tot_d, 2 * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    const long long nruns = c->det_totals_h[0];
+    if (c->det_totals_h[1] != c->det_totals_h[0]) return fail(c, GR80211_ERR_HIP, "frame detection: edge lists disagree");
+    if (nruns == 0) return GR80211_OK;
+    // per run: rise, fall, seen_at, scan_lo, prev_seen, pos (8 B each); rad, snr, rssi, emitted (4 B each)
+    if ((rc = ensure(c, c->det_runs, (size_t)nruns * 6 * 8))) return rc;
+    if ((rc = ensure(c, c->det_rec, (size_t)nruns * 4 * 4 + (size_t)(nruns / 256 + 2) * 4))) return rc;
+    long long *rise = (long long *)c->det_runs.p, *fall = rise + nruns, *seen_at = fall + nruns,
+              *scan_lo = seen_at + nruns, *prev_seen = scan_lo + nruns, *pos = prev_seen + nruns;
+    float *rad = (float *)c->det_rec.p, *snr = rad + nruns, *rssi = snr + nruns;
+    uint32_t *emitted = (uint32_t *)(rssi + nruns), *blk2 = emitted + nruns;
+    launch_det_edge_emit(mask, n, blk_r, blk_f, nruns, rise, fall, s);
+    launch_det_trigger_sync(d_iq, n, rise, fall, nruns, seen_at, scan_lo, prev_seen, pos, rad, snr, rssi, emitted, blk2,
+                            tot_d, s);
+    HIP_TRY(c, hipMemcpyAsync(c->det_totals_h + 2, tot_d + 2, 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    HIP_TRY(c, hipGetLastError());
+    *nruns_out = nruns;
+    *n_emit = (int)c->det_totals_h[2];
+    return GR80211_OK;
+}
+
+// The emitted sync bytes as descriptors (the first max_desc of them), after detect_core.
+void detect_emit(gr80211_ctx *c, hipStream_t s, long long nruns, long long n, gr80211_frame_desc *d_desc, int max_desc)
+{
+    long long *rise = (long long *)c->det_runs.p, *pos = rise + 5 * nruns;
+    float *rad = (float *)c->det_rec.p, *snr = rad + nruns, *rssi = snr + nruns;
+    uint32_t *emitted = (uint32_t *)(rssi + nruns), *blk2 = emitted + nruns;
+    launch_det_emit(emitted, nruns, blk2, pos, rad, snr, rssi, n, d_desc, max_desc, s);
+}
+
 }  // namespace
 
 extern "C" {
@@ -267,7 +314,7 @@ void gr80211_destroy(gr80211_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (Buf *b : {&c->desc, &c->ddesc, &c->info, &c->chan1, &c->chan2, &c->llr, &c->slot_frame, &c->groups, &c->dec,
                    &c->bitsw, &c->totals_d, &c->sched_ws, &c->blk_llr, &c->det_mask, &c->det_blk, &c->det_runs,
-                   &c->det_rec, &c->det_totals_d})
+                   &c->det_rec, &c->det_totals_d, &c->cap_desc, &c->cap_ws})
         release(*b);
     if (c->totals_h) (void)hipHostFree(c->totals_h);
     if (c->det_totals_h) (void)hipHostFree(c->det_totals_h);
@@ -320,39 +367,58 @@ int gr80211_detect(gr80211_ctx *c, const void *d_iq, uint64_t n_samples, gr80211
         return fail(c, GR80211_ERR_ARG, "gr80211_detect: bad argument");
     HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t s = pick(c, stream);
-    const long long n = (long long)n_samples;
-    int rc;
-    const int eb = det_edge_blocks(n);
-    if ((rc = ensure(c, c->det_mask, (size_t)det_mask_words(n) * 4))) return rc;
-    if ((rc = ensure(c, c->det_blk, (size_t)eb * 2 * 4 + 64))) return rc;
-    if ((rc = ensure(c, c->det_totals_d, 4 * 4))) return rc;
-    uint32_t *mask = (uint32_t *)c->det_mask.p;
-    uint32_t *blk_r = (uint32_t *)c->det_blk.p, *blk_f = blk_r + eb;
-    uint32_t *tot_d = (uint32_t *)c->det_totals_d.p;
-    launch_det_ac(d_iq, n, mask, s);
-    launch_det_edge_count(mask, n, blk_r, blk_f, tot_d, s);
-    HIP_TRY(c, hipMemcpyAsync(c->det_totals_h, tot_d, 2 * 4, hipMemcpyDeviceToHost, s));
-    HIP_TRY(c, hipStreamSynchronize(s));
-    const long long nruns = c->det_totals_h[0];
-    if (c->det_totals_h[1] != c->det_totals_h[0]) return fail(c, GR80211_ERR_HIP, "gr80211_detect: edge lists disagree");
-    if (nruns == 0) return GR80211_OK;
-    // per run: rise, fall, seen_at, scan_lo, prev_seen, pos (8 B each); rad, snr, rssi, emitted (4 B each)
-    if ((rc = ensure(c, c->det_runs, (size_t)nruns * 6 * 8))) return rc;
-    if ((rc = ensure(c, c->det_rec, (size_t)nruns * 4 * 4 + (size_t)(nruns / 256 + 2) * 4))) return rc;
-    long long *rise = (long long *)c->det_runs.p, *fall = rise + nruns, *seen_at = fall + nruns,
-              *scan_lo = seen_at + nruns, *prev_seen = scan_lo + nruns, *pos = prev_seen + nruns;
-    float *rad = (float *)c->det_rec.p, *snr = rad + nruns, *rssi = snr + nruns;
-    uint32_t *emitted = (uint32_t *)(rssi + nruns), *blk2 = emitted + nruns;
-    launch_det_edge_emit(mask, n, blk_r, blk_f, nruns, rise, fall, s);
-    launch_det_trigger_sync(d_iq, n, rise, fall, nruns, seen_at, scan_lo, prev_seen, pos, rad, snr, rssi, emitted, blk2,
-                            tot_d, s);
-    launch_det_emit(emitted, nruns, blk2, pos, rad, snr, rssi, n, d_desc, max_desc, s);
-    HIP_TRY(c, hipMemcpyAsync(c->det_totals_h + 2, tot_d + 2, 4, hipMemcpyDeviceToHost, s));
-    HIP_TRY(c, hipStreamSynchronize(s));
+    long long nruns = 0;
+    int rc = detect_core(c, s, d_iq, (long long)n_samples, &nruns, n_desc);
+    if (rc) return rc;
+    if (*n_desc == 0) return GR80211_OK;
+    detect_emit(c, s, nruns, (long long)n_samples, d_desc, max_desc);
     HIP_TRY(c, hipGetLastError());
-    *n_desc = (int)c->det_totals_h[2];
     if (*n_desc > max_desc) return fail(c, GR80211_ERR_ARG, "gr80211_detect: more sync points than max_desc");
     return GR80211_OK;
+}
+
+int gr80211_rx_capture(gr80211_ctx *c, const void *d_iq0, const void *d_iq1, uint64_t n_samples, uint8_t *d_out,
+                       int out_stride, int32_t *d_out_len, int32_t *d_n_pdu, int max_frames,
+                       gr80211_frame_desc *d_desc_out, int *n_frames, void *stream)
+{
+    if (!c) return GR80211_ERR_ARG;
+    if (!n_frames) return fail(c, GR80211_ERR_ARG, "gr80211_rx_capture: bad argument");
+    *n_frames = 0;
+    if (n_samples == 0) return GR80211_OK;
+    if (!d_iq0 || !d_out || !d_out_len || !d_n_pdu || out_stride < 8 || max_frames < 0 || n_samples > (1ull << 40))
+        return fail(c, GR80211_ERR_ARG, "gr80211_rx_capture: bad argument");
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = pick(c, stream);
+    const long long n = (long long)n_samples;
+    long long nruns = 0;
+    int nd = 0;
+    int rc = detect_core(c, s, d_iq0, n, &nruns, &nd);
+    if (rc) return rc;
+    if (nd == 0) return GR80211_OK;
+    if (nd > (1 << 20)) return fail(c, GR80211_ERR_ARG, "gr80211_rx_capture: at most 1048576 sync bytes per call");
+    // sync bytes -> L-SIG of each -> the ones `signal` deals with
+    if ((rc = ensure(c, c->cap_desc, (size_t)nd * 2 * sizeof(gr80211_frame_desc)))) return rc;
+    if ((rc = ensure(c, c->cap_ws, (size_t)(nd + 1) * 3 * sizeof(int32_t) + 64))) return rc;
+    gr80211_frame_desc *d_all = (gr80211_frame_desc *)c->cap_desc.p, *d_sel = d_all + nd;
+    int32_t *jump_a = (int32_t *)c->cap_ws.p, *jump_b = jump_a + nd + 1, *path = jump_b + nd + 1;
+    uint32_t *tot_d = (uint32_t *)c->det_totals_d.p;
+    detect_emit(c, s, nruns, n, d_all, nd);
+    const gr80211_frame_desc *dd = nullptr;
+    if ((rc = front_end(c, s, d_iq0, d_iq1, n_samples, d_all, nd, GR80211_FLAG_DESC_ON_DEVICE, &dd))) return rc;
+    launch_span_filter(d_all, (const gr80211_frame_info *)c->info.p, nd, n, jump_a, jump_b, path, d_sel, tot_d + 3, s);
+    HIP_TRY(c, hipMemcpyAsync(c->det_totals_h + 3, tot_d + 3, 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    const int nf = (int)c->det_totals_h[3];
+    *n_frames = nf;
+    if (nf > max_frames) return fail(c, GR80211_ERR_ARG, "gr80211_rx_capture: more frames than max_frames");
+    if (nf == 0) return GR80211_OK;
+    if (d_desc_out)
+        HIP_TRY(c, hipMemcpyAsync(d_desc_out, d_sel, (size_t)nf * sizeof(gr80211_frame_desc), hipMemcpyDeviceToDevice, s));
+    if ((rc = front_end(c, s, d_iq0, d_iq1, n_samples, d_sel, nf, GR80211_FLAG_DESC_ON_DEVICE, &dd))) return rc;
+    rc = run_decode_stages(c, s, nf, true, d_iq0, d_iq1, dd, nullptr, d_out, out_stride, d_out_len, d_n_pdu, nullptr, 0,
+                           true, nullptr, nullptr);
+    if (rc) return rc;
+    return finish_timing(c, s);
 }
 
 int gr80211_signal_batch(gr80211_ctx *c, const void *d_iq0, const void *d_iq1, uint64_t arena_len,

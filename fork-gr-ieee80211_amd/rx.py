@@ -53,7 +53,7 @@ assert FRAME_INFO_DTYPE.itemsize == C.sizeof(FrameInfo) == 112
 assert DEC_DESC_DTYPE.itemsize == C.sizeof(DecDesc) == 40
 
 EXPORTS = [
-    "gr80211_create", "gr80211_destroy", "gr80211_last_error", "gr80211_sync", "gr80211_rx_batch", "gr80211_signal_batch", "gr80211_detect",
+    "gr80211_create", "gr80211_destroy", "gr80211_last_error", "gr80211_sync", "gr80211_rx_batch", "gr80211_signal_batch", "gr80211_detect", "gr80211_rx_capture",
     "gr80211_demod_batch", "gr80211_decode_batch", "gr80211_dev_alloc", "gr80211_dev_free",
     "gr80211_copy_h2d", "gr80211_copy_d2h", "gr80211_set_profiling", "gr80211_last_timing",
     "gr80211_version", "gr80211_table_checksum",
@@ -79,6 +79,7 @@ def load_library():
     L.gr80211_sync.argtypes = [vp, vp]
     L.gr80211_rx_batch.argtypes = [vp, vp, vp, C.c_uint64, vp, C.c_int, C.c_uint, vp, C.c_int, vp, vp, vp, vp]
     L.gr80211_detect.argtypes = [vp, vp, C.c_uint64, vp, C.c_int, C.POINTER(C.c_int), vp]
+    L.gr80211_rx_capture.argtypes = [vp, vp, vp, C.c_uint64, vp, C.c_int, vp, vp, C.c_int, vp, C.POINTER(C.c_int), vp]
     L.gr80211_signal_batch.argtypes = [vp, vp, vp, C.c_uint64, vp, C.c_int, C.c_uint, vp, vp]
     L.gr80211_demod_batch.argtypes = [vp, vp, vp, C.c_uint64, vp, C.c_int, C.c_uint, vp, C.POINTER(vp),
                                       C.POINTER(C.c_uint64), vp]
@@ -232,6 +233,25 @@ class RxContext:
                                      max_desc, C.byref(n), self._stream())
         self._check(rc, "gr80211_detect")
         return desc, n.value
+
+    def rx_capture(self, iq0, iq1=None, max_frames=None, out_stride=4104):
+        """Raw capture(s) -> PDUs.  Returns dict(out, out_len, n_pdu, desc (bytes), n) with n frames in stream order."""
+        t = self.torch
+        assert iq0.is_cuda and iq0.dtype == t.complex64 and iq0.is_contiguous()
+        if max_frames is None:
+            max_frames = iq0.numel() // 400 + 16
+        m = max(max_frames, 1)
+        out = t.zeros((m, out_stride), dtype=t.uint8, device=self.dev)
+        out_len = t.zeros(m, dtype=t.int32, device=self.dev)
+        n_pdu = t.zeros(m, dtype=t.int32, device=self.dev)
+        desc = t.zeros(m * FRAME_DESC_DTYPE.itemsize, dtype=t.uint8, device=self.dev)
+        n = C.c_int(0)
+        rc = self.lib.gr80211_rx_capture(
+            self.h, C.c_void_p(iq0.data_ptr()), C.c_void_p(iq1.data_ptr()) if iq1 is not None else None, iq0.numel(),
+            C.c_void_p(out.data_ptr()), out_stride, C.c_void_p(out_len.data_ptr()), C.c_void_p(n_pdu.data_ptr()),
+            max_frames, C.c_void_p(desc.data_ptr()), C.byref(n), self._stream())
+        self._check(rc, "gr80211_rx_capture")
+        return dict(out=out, out_len=out_len, n_pdu=n_pdu, desc=desc, n=n.value)
 
     def signal_batch(self, iq0, iq1, desc, n_frames):
         """IQ -> per-frame tag records only (L-SIG, format detection, SIG fields).  Returns the info ndarray."""

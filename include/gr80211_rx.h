@@ -130,6 +130,19 @@ int gr80211_detect(gr80211_ctx *ctx, const void *d_iq, uint64_t n_samples, gr802
                    int *n_desc, void *stream);
 
 /*
+ * Raw capture in, PDUs out: presiso -> trigger -> sync -> signal(2) -> demod(2) -> decode (examples/rx.grc,
+ * examples/rx2.grc) over one capture.  Detection runs on antenna 1 (d_iq0) as in the reference flowgraphs.  Of the
+ * sync bytes found, the frames are the ones `signal` deals with: after a frame's 224 + nsamp samples (80 after a
+ * failed L-SIG check) it resumes its search, sync bytes in between are ignored (lib/signal_impl.cc:75-106,153-202).
+ * Slot i of d_out / d_out_len / d_n_pdu belongs to the i-th such sync byte in stream order; d_desc_out (nullable,
+ * max_frames entries) receives their descriptors.  *n_frames (host) = their number; more than max_frames is an
+ * error.
+ */
+int gr80211_rx_capture(gr80211_ctx *ctx, const void *d_iq0, const void *d_iq1, uint64_t n_samples, uint8_t *d_out,
+                       int out_stride, int32_t *d_out_len, int32_t *d_n_pdu, int max_frames,
+                       gr80211_frame_desc *d_desc_out, int *n_frames, void *stream);
+
+/*
  * signal/signal2 (and the format detection of demod/demod2) only: L-SIG decode, format detection,
  * HT-SIG / VHT-SIG-A / VHT-SIG-B decode and channel estimation of every frame, no data symbols.
  * d_info[i] receives status, L-SIG mcs/len, nsamp (the number of samples `signal` forwards after

@@ -5,7 +5,7 @@ to tolerance and the inputs keep clear of the 0.3 plateau threshold's rounding m
 import numpy as np
 import pytest
 
-from util import H22, golden_frames, ref_fixtures
+from util import H22, blob_of, golden_frames, model_chain, ref_fixtures
 
 pytestmark = pytest.mark.gpu
 
@@ -114,3 +114,64 @@ def test_detect_then_decode(pkg, rxctx, oracle):
     out = res["out"].cpu().numpy()
     for i, f in enumerate(frames):
         assert bytes(out[i, 3: out_len[i] - 1]) == f["mpdu"], f["name"]
+
+
+def capture_pdus(rxctx, x0, x1=None):
+    import torch
+    d0 = torch.from_numpy(np.ascontiguousarray(x0, np.complex64)).cuda()
+    d1 = torch.from_numpy(np.ascontiguousarray(x1, np.complex64)).cuda() if x1 is not None else None
+    r = rxctx.rx_capture(d0, d1, out_stride=1600)
+    rxctx.sync()
+    n = r["n"]
+    out_len = r["out_len"].cpu().numpy()[:n]
+    out = r["out"].cpu().numpy()[:n]
+    pdus = []
+    for i in range(n):
+        blob, at = bytes(out[i, : out_len[i]]), 0
+        while at + 4 <= len(blob):
+            ln = blob[at + 1] | (blob[at + 2] << 8)
+            pdus.append(blob[at: at + ln + 4])
+            at += ln + 4
+    return pdus, n
+
+
+def test_capture_to_pdus_with_false_sync_bytes(pkg, rxctx, oracle):
+    """gr80211_rx_capture against the chain presiso -> trigger -> sync -> signal -> demod -> decode of the oracle.
+    A 16-periodic burst inside a frame's payload and another one on its own make sync bytes that `signal` must
+    ignore (inside a frame) or drop after a failed L-SIG check."""
+    frames = [f for f in golden_frames() if f["nss"] == 1]
+    parts = [f["iq"][0].astype(np.complex64) for f in frames]
+    x = np.concatenate(parts + [np.zeros(900, np.complex64)])
+    t = np.arange(len(x))
+    tone = (0.25 * np.exp(2j * np.pi * t / 16.0)).astype(np.complex64)
+    x[1500:1900] += tone[1500:1900]                    # inside frame 0's payload
+    tail = len(x) - 800
+    x[tail: tail + 500] += tone[tail: tail + 500]        # after the last frame
+    x = noisy(x, 0.003, 21)
+    det = oracle.detect(x)
+    assert len(det["pos"]) > len(frames)
+    want, n_ok = model_chain(oracle, x, None, list(zip(det["pos"].tolist(), det["rad"].tolist())))
+    got, n = capture_pdus(rxctx, x)
+    assert n == model_chain.dealt_with
+    assert got == want
+    # the burst destroys frame 0's payload (no FCS pass); every other frame comes back
+    assert [p[3:-1] for p in got] == [f["mpdu"] for f in frames[1:]]
+
+
+def test_capture_two_antennas(pkg, rxctx, oracle):
+    parts = []
+    sent = []
+    for f in golden_frames():
+        if f["nss"] == 2:
+            parts.append((H22 @ f["iq"]).astype(np.complex64))
+            sent.append(f["mpdu"])
+    name, ants, sidx = ref_fixtures()[1]
+    parts.append(np.stack(ants))
+    x = np.concatenate(parts + [np.zeros((2, 400), np.complex64)], axis=1)
+    rng = np.random.default_rng(4)
+    x = (x + 0.002 * (rng.standard_normal(x.shape) + 1j * rng.standard_normal(x.shape))).astype(np.complex64)
+    det = oracle.detect(x[0])
+    want, n_ok = model_chain(oracle, x[0], x[1], list(zip(det["pos"].tolist(), det["rad"].tolist())))
+    got, n = capture_pdus(rxctx, x[0], x[1])
+    assert got == want and n == model_chain.dealt_with
+    assert [p[3:-1] for p in got][: len(sent)] == sent

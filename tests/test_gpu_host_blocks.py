@@ -8,13 +8,12 @@ import subprocess
 import numpy as np
 import pytest
 
-from util import H22, golden_frames, ref_fixtures
+from util import H22, blob_of, golden_frames, model_chain, ref_fixtures
 
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PUMP = os.path.join(ROOT, "fork-gr-ieee80211_amd", "gr80211_pump")
-ST_DROP_LSIG = 1
 
 
 def run_pump(args):
@@ -24,32 +23,6 @@ def run_pump(args):
     pdus = [bytes.fromhex(l.split()[1]) for l in p.stdout.splitlines() if l.startswith("PDU ")]
     stat = [l for l in p.stdout.splitlines() if l.startswith("STAT")]
     return pdus, stat[0] if stat else ""
-
-
-def blob_of(p):
-    n = len(p["mpdu"])
-    return bytes([p["format"], n % 256, n // 256]) + p["mpdu"] + bytes([p["mcs"]])
-
-
-def model_chain(oracle, iq0, iq1, triggers):
-    """What signal -> demod -> decode publish for a stream with tagged sync bytes at `triggers`."""
-    out, cursor, n_frames = [], 0, 0
-    for pos, rad in sorted(triggers):
-        if pos < cursor:
-            continue  # inside the previous frame: the trigger search has not resumed yet
-        if len(iq0) - pos < 224:
-            break
-        r = oracle.rx_frame(iq0, iq1, pos, rad, want_llr=False)
-        if r["status"] == ST_DROP_LSIG:
-            cursor = pos + 80
-            continue
-        span = 224 + max(int(r["frame"].nsamp), 0)
-        end = min(len(iq0), pos + span)
-        r = oracle.rx_frame(iq0[:end], None if iq1 is None else iq1[:end], pos, rad, want_llr=False)
-        out += [blob_of(p) for p in r["pdus"]]
-        n_frames += 1
-        cursor = pos + span
-    return out, n_frames
 
 
 def write_stream(tmp_path, iq0, iq1, triggers):

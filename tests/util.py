@@ -60,3 +60,36 @@ def awgn(sig, snr_db, rng):
 
 def unpack_bits(bytes_row, nbits):
     return np.unpackbits(np.asarray(bytes_row, dtype=np.uint8), bitorder="little")[:nbits]
+
+
+ST_DROP_LSIG = 1
+
+
+def blob_of(p):
+    n = len(p["mpdu"])
+    return bytes([p["format"], n % 256, n // 256]) + p["mpdu"] + bytes([p["mcs"]])
+
+
+def model_chain(oracle, iq0, iq1, triggers):
+    """What signal -> demod -> decode publish for a stream with tagged sync bytes at `triggers`."""
+    out, cursor, n_frames = [], 0, 0
+    model_chain.dealt_with = 0
+    for pos, rad in sorted(triggers):
+        if pos < cursor:
+            continue  # inside the previous frame: the trigger search has not resumed yet
+        if len(iq0) - pos < 224:
+            break
+        r = oracle.rx_frame(iq0, iq1, pos, rad, want_llr=False)
+        model_chain.dealt_with += 1
+        if r["status"] == ST_DROP_LSIG:
+            cursor = pos + 80
+            continue
+        span = 224 + max(int(r["frame"].nsamp), 0)
+        end = min(len(iq0), pos + span)
+        r = oracle.rx_frame(iq0[:end], None if iq1 is None else iq1[:end], pos, rad, want_llr=False)
+        out += [blob_of(p) for p in r["pdus"]]
+        n_frames += 1
+        cursor = pos + span
+    return out, n_frames
+
+
