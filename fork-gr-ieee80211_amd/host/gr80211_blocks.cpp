@@ -465,5 +465,81 @@ bool rx::process(bool final)
     return true;
 }
 
+// ------------------------------------------------------------------------------------ capture_rx
+capture_rx::sptr capture_rx::make(int n_rx, int device) { return sptr(new capture_rx(n_rx, device)); }
+
+capture_rx::capture_rx(int n_rx, int device) : block(n_rx == 2 ? 2 : 1), d_nrx(n_rx == 2 ? 2 : 1), d_gpu(device)
+{
+    if (!d_gpu.ok()) d_err = "gr80211_create failed";
+}
+
+capture_rx::~capture_rx() {}
+
+void capture_rx::forecast(int noutput_items, gr_vector_int &ninput_items_required)
+{
+    for (int &v : ninput_items_required) v = noutput_items;
+}
+
+int capture_rx::general_work(int, gr_vector_int &ninput_items, gr_vector_const_void_star &input_items, gr_vector_void_star &)
+{
+    int n = ninput_items[0];
+    if (d_nrx == 2) n = std::min(n, ninput_items[1]);
+    for (int a = 0; a < d_nrx; a++) {
+        const gr_complex *s = static_cast<const gr_complex *>(input_items[a]);
+        d_hold[a].insert(d_hold[a].end(), s, s + n);
+    }
+    consume_each(n);
+    return 0;
+}
+
+bool capture_rx::flush()
+{
+    const size_t n = d_hold[0].size();
+    if (n == 0) return true;
+    if (!d_gpu.ok()) return false;
+    gr80211_ctx *c = d_gpu.ctx();
+    void *diq0 = d_gpu.buffer(0, (n + 64) * sizeof(gr_complex));
+    void *diq1 = d_nrx == 2 ? d_gpu.buffer(1, (n + 64) * sizeof(gr_complex)) : nullptr;
+    // a frame needs at least 400 samples of preamble; sync bytes whose L-SIG check fails also take a slot
+    const int max_frames = (int)std::min<size_t>(n / 80 + 16, (size_t)1 << 20);
+    uint8_t *dout = static_cast<uint8_t *>(d_gpu.buffer(3, (size_t)max_frames * OUT_STRIDE));
+    int32_t *dlen = static_cast<int32_t *>(d_gpu.buffer(4, (size_t)max_frames * 4));
+    int32_t *dnp = static_cast<int32_t *>(d_gpu.buffer(5, (size_t)max_frames * 4));
+    if (!diq0 || (d_nrx == 2 && !diq1) || !dout || !dlen || !dnp) {
+        d_err = "device allocation failed";
+        return false;
+    }
+    int nf = 0;
+    if (gr80211_copy_h2d(c, diq0, d_hold[0].data(), n * sizeof(gr_complex), nullptr) != GR80211_OK ||
+        (d_nrx == 2 && gr80211_copy_h2d(c, diq1, d_hold[1].data(), n * sizeof(gr_complex), nullptr) != GR80211_OK) ||
+        gr80211_rx_capture(c, diq0, diq1, n, dout, OUT_STRIDE, dlen, dnp, max_frames, nullptr, &nf, nullptr) != GR80211_OK) {
+        d_err = d_gpu.error();
+        return false;
+    }
+    std::vector<uint8_t> out((size_t)nf * OUT_STRIDE);
+    std::vector<int32_t> len(nf);
+    if (nf > 0 && (gr80211_copy_d2h(c, len.data(), dlen, (size_t)nf * 4, nullptr) != GR80211_OK ||
+                   gr80211_copy_d2h(c, out.data(), dout, out.size(), nullptr) != GR80211_OK)) {
+        d_err = d_gpu.error();
+        return false;
+    }
+    d_nFrames += (uint64_t)nf;
+    for (int i = 0; i < nf; i++) {
+        const uint8_t *p = &out[(size_t)i * OUT_STRIDE];
+        int at = 0;
+        while (at + 4 <= len[i]) {
+            const int L = p[at + 1] | (p[at + 2] << 8);
+            pdu_t m;
+            m.blob.assign(p + at, p + at + L + 4);
+            m.len = L + 4;
+            message_port_pub("out", m);
+            d_nPdu++;
+            at += L + 4;
+        }
+    }
+    for (int a = 0; a < d_nrx; a++) d_hold[a].clear();
+    return true;
+}
+
 }  // namespace host
 }  // namespace gr80211

@@ -169,5 +169,32 @@ private:
     uint64_t d_nTrig = 0, d_nFrames = 0, d_nPdu = 0;
 };
 
+// Whole receive flowgraph of examples/rx.grc / rx2.grc for a recorded capture: inputs are the antenna streams only
+// ({c64} or {c64, c64}); presiso -> trigger -> sync -> signal(2) -> demod(2) -> decode run on the GPU in one call
+// (gr80211_rx_capture) when the stream ends.  general_work only collects samples: detection keeps state across
+// the whole stream (plateaus, countdowns, the 111 items sync skips), so a capture is processed in one piece.
+class capture_rx : public block
+{
+public:
+    typedef std::shared_ptr<capture_rx> sptr;
+    static sptr make(int n_rx = 1, int device = 0);
+    ~capture_rx() override;
+
+    void forecast(int noutput_items, gr_vector_int &ninput_items_required) override;
+    int general_work(int noutput_items, gr_vector_int &ninput_items, gr_vector_const_void_star &input_items,
+                     gr_vector_void_star &output_items) override;
+    bool flush() override;
+
+    uint64_t frames_decoded() const { return d_nFrames; }
+    uint64_t pdus_published() const { return d_nPdu; }
+
+private:
+    capture_rx(int n_rx, int device);
+    int d_nrx;
+    gpu_session d_gpu;
+    std::vector<gr_complex> d_hold[2];
+    uint64_t d_nFrames = 0, d_nPdu = 0;
+};
+
 }  // namespace host
 }  // namespace gr80211

@@ -3,6 +3,8 @@
 //
 //   gr80211_pump rx <n_rx> <chunk> <batch> <triggers.txt> <iq0.bin> [iq1.bin]
 //       triggers.txt: one "pos rad snr rssi" line per tagged sync byte; iq*.bin: interleaved float32 I/Q
+//   gr80211_pump capture <n_rx> <chunk> <iq0.bin> [iq1.bin]
+//       no sync stream: frame detection runs on the GPU as well
 //   gr80211_pump decode <chunk> <batch> <tags.txt> <llr.bin>
 //       tags.txt: one "offset format len total cr mcs ampdu trellis" line per packet; llr.bin: float32
 //
@@ -113,6 +115,28 @@ int main(int argc, char **argv)
                (unsigned long long)b->frames_decoded(), (unsigned long long)b->pdus_published());
         return ok ? 0 : 1;
     }
+    if (argc >= 5 && !strcmp(argv[1], "capture")) {
+        const int n_rx = atoi(argv[2]), chunk = atoi(argv[3]);
+        std::vector<char> iq0, iq1;
+        if (!read_file(argv[4], iq0) || (n_rx == 2 && (argc < 6 || !read_file(argv[5], iq1)))) {
+            fprintf(stderr, "cannot read IQ file\n");
+            return 2;
+        }
+        size_t n = iq0.size() / 8;
+        if (n_rx == 2) n = std::min(n, iq1.size() / 8);
+        capture_rx::sptr b = capture_rx::make(n_rx, 0);
+        b->set_msg_handler(on_msg);
+        std::vector<const char *> ports = {iq0.data()};
+        std::vector<size_t> isz = {8};
+        if (n_rx == 2) {
+            ports.push_back(iq1.data());
+            isz.push_back(8);
+        }
+        const bool ok = pump(*b, ports, isz, n, chunk);
+        printf("STAT frames=%llu pdus=%llu\n", (unsigned long long)b->frames_decoded(),
+               (unsigned long long)b->pdus_published());
+        return ok ? 0 : 1;
+    }
     if (argc >= 6 && !strcmp(argv[1], "decode")) {
         const int chunk = atoi(argv[2]), batch = atoi(argv[3]);
         std::vector<char> llr;
@@ -144,6 +168,7 @@ int main(int argc, char **argv)
         return ok ? 0 : 1;
     }
     fprintf(stderr, "usage: gr80211_pump rx <n_rx> <chunk> <batch> <triggers.txt> <iq0.bin> [iq1.bin]\n"
+                    "       gr80211_pump capture <n_rx> <chunk> <iq0.bin> [iq1.bin]\n"
                     "       gr80211_pump decode <chunk> <batch> <tags.txt> <llr.bin>\n");
     return 2;
 }

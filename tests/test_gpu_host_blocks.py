@@ -155,3 +155,16 @@ def test_decode_block_stream(tmp_path, pkg, rxctx, oracle, chunk, batch):
     assert got == want
     assert "packets=%d " % len(tags) in stat + " ", stat
     assert [p[3:-1] for p in got] == [f["mpdu"] for f in frames]
+
+
+def test_capture_block_raw_stream(tmp_path, oracle):
+    """capture_rx: antenna stream only; detection, `signal`'s trigger search and the RX path all run on the GPU."""
+    iq0, triggers, frames = siso_stream(0.003, 6)
+    det = oracle.detect(iq0)
+    want, n_ok = model_chain(oracle, iq0, None, list(zip(det["pos"].tolist(), det["rad"].tolist())))
+    f0 = tmp_path / "iq0.bin"
+    iq0.astype(np.complex64).tofile(f0)
+    got, stat = run_pump(["capture", 1, 5000, f0])
+    assert got == want
+    assert [p[3:-1] for p in got] == [f["mpdu"] for f in frames]
+    assert "frames=%d " % model_chain.dealt_with in stat + " ", stat
