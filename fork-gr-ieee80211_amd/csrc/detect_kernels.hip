@@ -20,10 +20,6 @@ namespace gr80211 {
 
 namespace {
 
-constexpr int AC_TILE = 2048;   // samples per workgroup of k_det_ac
-constexpr int AC_HALO = 80;     // 63 (power window) + 16 (lag) rounded up
-constexpr int AC_THREADS = 256;
-constexpr int AC_PER_THREAD = AC_TILE / AC_THREADS;  // 8
 constexpr float PLATEAU_AC = 0.3f;   // lib/trigger_impl.cc:78
 constexpr int PLATEAU_LEN = 20;      // lib/trigger_impl.cc:87
 constexpr int COUNT_DOWN = 80;       // lib/trigger_impl.cc:91
@@ -58,92 +54,97 @@ __device__ __forceinline__ float cabs_ref(float x, float y)
 
 // -----------------------------------------------------------------------------------------
 // k_det_ac: bit n of `mask` = ( |sum_{k<48} x[n-k-16] conj(x[n-k])| / sum_{k<64} |x[n-k]|^2 > 0.3 ).
-// The window sums are differences of workgroup-local prefix sums held in double: exact to float rounding,
-// where the reference's running float sums drift.  Reads 8 B per sample once, writes 1 bit per sample.
+// One wave walks AC_ROWS rows of 64 consecutive samples, lane = sample (one coalesced 512-byte load per row, the
+// next row in flight while this one is worked on).  The window sums come from inclusive scans across the lanes
+// (six DPP adds each) of this row and the previous one: sum over the last 64 samples = S[l] + (T' - S'[l]),
+// over the last 48 = S[l] - S[l-48] or S[l] + (T' - S'[l+16]).  No sum is longer than 64 terms, so nothing
+// drifts the way the reference's running sums do.  Reads 8 B per sample once, writes 1 bit per sample.
 // -----------------------------------------------------------------------------------------
-__global__ __launch_bounds__(AC_THREADS) void k_det_ac(const c32d *__restrict__ x, long long n, uint32_t *__restrict__ mask)
+constexpr int AC_ROWS = 64;
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float scan_step(float v)
 {
-    __shared__ c32d s_x[AC_TILE + AC_HALO];
-    __shared__ double s_pr[AC_TILE + 64], s_pi[AC_TILE + 64], s_pp[AC_TILE + 64];
-    __shared__ double s_wr[AC_THREADS / 64][3];
-    const long long t0 = (long long)blockIdx.x * AC_TILE;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int i = tid; i < AC_TILE + AC_HALO; i += AC_THREADS) s_x[i] = ld(x, t0 - AC_HALO + i, n);
-    __syncthreads();
-    // element e (0 .. AC_TILE+63) stands for sample t0 - 64 + e; each thread owns a run of consecutive elements
-    constexpr int NE = AC_TILE + 64;
-    constexpr int PER = (NE + AC_THREADS - 1) / AC_THREADS;  // 9
-    double ar[PER], ai[PER], ap[PER];
-    double sr = 0.0, si = 0.0, sp = 0.0;
-#pragma unroll
-    for (int k = 0; k < PER; k++) {
-        const int e = tid * PER + k;
-        double mr = 0.0, mi = 0.0, pw = 0.0;
-        if (e < NE) {
-            const c32d a = s_x[e + 16 - 16];  // x[n-16]: s_x index of sample t0-64+e is e+16
-            const c32d b = s_x[e + 16];
-            // multiply_conjugate_cc: a * conj(b)
-            mr = (double)(a.x * b.x + a.y * b.y);
-            mi = (double)(a.y * b.x - a.x * b.y);
-            pw = (double)(b.x * b.x + b.y * b.y);
+    // lanes the control does not reach add 0
+    const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false);
+    return v + __int_as_float(moved);
+}
+
+// inclusive prefix sum over the 64 lanes
+__device__ __forceinline__ float wave_scan(float v)
+{
+    v = scan_step<0x111, 0xf>(v);  // row_shr:1
+    v = scan_step<0x112, 0xf>(v);  // row_shr:2
+    v = scan_step<0x114, 0xf>(v);  // row_shr:4
+    v = scan_step<0x118, 0xf>(v);  // row_shr:8
+    v = scan_step<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
+    v = scan_step<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
+struct row_sums {
+    float sr, si, sp;  // inclusive scans of the lag product (re, im) and of the power
+    float tr, ti, tp;  // row totals
+};
+
+// scans of the row whose samples are xc, given the previous row's samples xq (for x[n-16] of the first 16 lanes)
+__device__ __forceinline__ row_sums scan_row(c32d xc, c32d xq, int lane)
+{
+    const int src = (lane + 48) & 63;  // lane - 16, wrapping into the previous row
+    const float ax = __shfl(xc.x, src), ay = __shfl(xc.y, src);
+    const float bx = __shfl(xq.x, src), by = __shfl(xq.y, src);
+    c32d a;  // x[n-16]
+    a.x = lane >= 16 ? ax : bx;
+    a.y = lane >= 16 ? ay : by;
+    // multiply_conjugate_cc: a * conj(x)
+    const float mr = a.x * xc.x + a.y * xc.y;
+    const float mi = a.y * xc.x - a.x * xc.y;
+    const float pw = xc.x * xc.x + xc.y * xc.y;
+    row_sums r;
+    r.sr = wave_scan(mr);
+    r.si = wave_scan(mi);
+    r.sp = wave_scan(pw);
+    r.tr = __shfl(r.sr, 63);
+    r.ti = __shfl(r.si, 63);
+    r.tp = __shfl(r.sp, 63);
+    return r;
+}
+
+__global__ __launch_bounds__(256) void k_det_ac(const c32d *__restrict__ x, long long n, uint32_t *__restrict__ mask)
+{
+    const int lane = threadIdx.x & 63;
+    const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long base = wave * (long long)(AC_ROWS * 64);
+    if (base >= n) return;
+    const long long nwords = (n + 31) >> 5;
+    // the row before this wave's first one seeds the window sums
+    c32d xq = ld(x, base - 128 + lane, n);
+    c32d xp = ld(x, base - 64 + lane, n);
+    row_sums prev = scan_row(xp, xq, lane);
+    c32d xn = ld(x, base + lane, n);
+    for (int r = 0; r < AC_ROWS; r++) {
+        const long long n0 = base + (long long)r * 64;
+        if (n0 >= n) break;
+        const c32d xc = xn;
+        xn = ld(x, n0 + 64 + lane, n);
+        const row_sums cur = scan_row(xc, xp, lane);
+        // 48-sample window of the lag product
+        const int s48 = (lane + 16) & 63;  // lane - 48, wrapping
+        const float cr48 = __shfl(cur.sr, s48), ci48 = __shfl(cur.si, s48);
+        const float pr48 = __shfl(prev.sr, s48), pi48 = __shfl(prev.si, s48);
+        const float wr = lane >= 48 ? cur.sr - cr48 : cur.sr + (prev.tr - pr48);
+        const float wi = lane >= 48 ? cur.si - ci48 : cur.si + (prev.ti - pi48);
+        // 64-sample window of the power
+        const float wp = cur.sp + (prev.tp - prev.sp);
+        const float ac = sqrtf(wr * wr + wi * wi) / wp;  // complex_to_mag, divide
+        const unsigned long long bits = __ballot(n0 + lane < n && ac > PLATEAU_AC);
+        if (lane == 0) {
+            const long long w = n0 >> 5;
+            if (w < nwords) mask[w] = (uint32_t)bits;
+            if (w + 1 < nwords) mask[w + 1] = (uint32_t)(bits >> 32);
         }
-        sr += mr;
-        si += mi;
-        sp += pw;
-        ar[k] = sr;
-        ai[k] = si;
-        ap[k] = sp;
-    }
-    // exclusive scan of the thread totals: within the wave, then across the four waves
-    double xr = sr, xi = si, xp = sp;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const double ur = __shfl_up(xr, d), ui = __shfl_up(xi, d), up = __shfl_up(xp, d);
-        if (lane >= d) {
-            xr += ur;
-            xi += ui;
-            xp += up;
-        }
-    }
-    if (lane == 63) {
-        s_wr[wave][0] = xr;
-        s_wr[wave][1] = xi;
-        s_wr[wave][2] = xp;
-    }
-    __syncthreads();
-    double br = xr - sr, bi = xi - si, bp = xp - sp;
-    for (int w = 0; w < wave; w++) {
-        br += s_wr[w][0];
-        bi += s_wr[w][1];
-        bp += s_wr[w][2];
-    }
-#pragma unroll
-    for (int k = 0; k < PER; k++) {
-        const int e = tid * PER + k;
-        if (e < NE) {
-            s_pr[e] = br + ar[k];
-            s_pi[e] = bi + ai[k];
-            s_pp[e] = bp + ap[k];
-        }
-    }
-    __syncthreads();
-    // sample j of the tile is element e = j + 64; window sums over the last 48 / 64 elements
-    uint32_t bits = 0;
-#pragma unroll
-    for (int k = 0; k < AC_PER_THREAD; k++) {
-        const int j = tid * AC_PER_THREAD + k;
-        const int e = j + 64;
-        const float cr = (float)(s_pr[e] - s_pr[e - 48]);
-        const float ci = (float)(s_pi[e] - s_pi[e - 48]);
-        const float pw = (float)(s_pp[e] - s_pp[e - 64]);
-        const float ac = sqrtf(cr * cr + ci * ci) / pw;  // complex_to_mag, divide
-        if (t0 + j < n && ac > PLATEAU_AC) bits |= 1u << k;
-    }
-    // four neighbouring threads hold the 32 bits of one mask word
-    const uint32_t b1 = __shfl_down(bits, 1), b2 = __shfl_down(bits, 2), b3 = __shfl_down(bits, 3);
-    if ((tid & 3) == 0) {
-        const long long w = (t0 >> 5) + (tid >> 2);
-        if (w * 32 < n) mask[w] = bits | (b1 << 8) | (b2 << 16) | (b3 << 24);
+        xp = xc;
+        prev = cur;
     }
 }
 
@@ -611,8 +612,8 @@ int det_edge_blocks(long long n) { return (int)((det_mask_words(n) + EDGE_WORDS)
 
 void launch_det_ac(const void *iq, long long n, uint32_t *mask, hipStream_t s)
 {
-    const int nblk = (int)((n + AC_TILE - 1) / AC_TILE);
-    hipLaunchKernelGGL(k_det_ac, dim3(nblk), dim3(AC_THREADS), 0, s, (const c32d *)iq, n, mask);
+    const long long waves = (n + AC_ROWS * 64 - 1) / (AC_ROWS * 64);
+    hipLaunchKernelGGL(k_det_ac, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, (const c32d *)iq, n, mask);
 }
 
 void launch_det_edge_count(const uint32_t *mask, long long n, uint32_t *blk_rise, uint32_t *blk_fall, uint32_t *totals,
