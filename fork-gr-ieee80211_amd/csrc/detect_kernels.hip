@@ -8,8 +8,8 @@
 //   k_det_edges   rising / falling edges of that bit stream = trigger's plateaus ("runs"), in order;
 //   k_det_trigger trigger's plateau counter / 80-sample countdown and sync's "111 items consumed per
 //                 trigger" rule, replayed per chain of runs that are close enough to influence each other;
-//   k_det_sync    per trigger: the conjugate average sync would hold at that moment, the 64-lag L-LTF
-//                 autocorrelation over 111 positions, its 80 % shoulder midpoint, CFO, SNR, RSSI;
+//   k_det_sync    per trigger (one wave each): the conjugate average sync would hold at that moment, the 64-lag
+//                 L-LTF autocorrelation over 111 positions, its 80 % shoulder midpoint, CFO, SNR, RSSI;
 //   k_det_emit    the sync bytes that were produced, in stream order, as frame descriptors.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -327,50 +327,61 @@ __global__ void k_det_trigger(const long long *__restrict__ rise, const long lon
 }
 
 // -----------------------------------------------------------------------------------------
-// k_det_sync: one thread per run whose trigger sync acts on.
+// k_det_sync: one wave per run whose trigger byte sync acts on.
+//   1. The conjugate average sync holds when it meets the byte (lib/sync_impl.cc:85-88): the 48-sample lag sum at
+//      the last "new maximum" flag (trigger bit 1, lib/trigger_impl.cc:81-86) it scanned -- the first position of
+//      the maximum of the autocorrelation over the latest plateau before the byte.  The autocorrelation is
+//      recomputed with k_det_ac's row scans on the same 64-sample grid, so it is the value the plateau bits came
+//      from.  Flags inside the 111 items sync skipped after an earlier byte were never seen; then the value found
+//      for that earlier byte is still in place.
+//   2. The 64-lag L-LTF autocorrelation over 111 positions (lib/sync_impl.cc:139-171): the 240 samples go to
+//      LDS, lanes compute |x|^2 and the lag products in parallel, then the three running sums are stepped in the
+//      reference's order (a short dependent chain of float adds; every lane steps it and keeps the sums of its
+//      own positions), and lanes finish their positions in parallel.
+//   3. Maximum (first), 80 % shoulders by ballot, midpoint; CFO (lib/sync_impl.cc:173-191) with the 128 rotations
+//      spread over the lanes and the 64 products summed in order.
 // -----------------------------------------------------------------------------------------
 namespace {
 
-// presiso's two window sums at sample i, from scratch (double accumulation, float products as the blocks make them)
-__device__ void window_sums(const c32d *x, long long n, long long i, double &cr, double &ci, double &pw)
+// first position of the maximum of ac over [a, hi) if it is >= lo (else -1) and the lag sum there
+__device__ long long plateau_peak(const c32d *x, long long n, long long a, long long hi, long long lo, int lane, float &vr,
+                                  float &vi)
 {
-    cr = ci = pw = 0.0;
-    for (int k = 0; k < 64; k++) {
-        const c32d b = ld(x, i - k, n);
-        pw += (double)(b.x * b.x + b.y * b.y);
-        if (k < 48) {
-            const c32d a = ld(x, i - k - 16, n);
-            cr += (double)(a.x * b.x + a.y * b.y);
-            ci += (double)(a.y * b.x - a.x * b.y);
-        }
-    }
-}
-
-// Position of the last "new maximum" flag (trigger bit 1, lib/trigger_impl.cc:81-86) in [lo, hi) of the run that
-// starts at a: the first position of the maximum of ac over [a, hi), provided it is >= lo; -1 otherwise.
-__device__ long long last_max_flag(const c32d *x, long long n, long long a, long long hi, long long lo, float &vr, float &vi)
-{
-    double cr, ci, pw;
-    window_sums(x, n, a, cr, ci, pw);
-    float best = 0.0f;
+    const long long row0 = a >> 6, row1 = (hi - 1) >> 6;
+    c32d xq = ld(x, (row0 - 2) * 64 + lane, n);
+    c32d xp = ld(x, (row0 - 1) * 64 + lane, n);
+    row_sums prev = scan_row(xp, xq, lane);
+    float best = 0.0f, br = 0.0f, bi = 0.0f;
     long long at = -1;
-    for (long long i = a; i < hi; i++) {
-        if (i > a) {
-            const c32d b = ld(x, i, n), a16 = ld(x, i - 16, n);
-            const c32d ob = ld(x, i - 48, n), oa = ld(x, i - 64, n);
-            cr += (double)(a16.x * b.x + a16.y * b.y) - (double)(oa.x * ob.x + oa.y * ob.y);
-            ci += (double)(a16.y * b.x - a16.x * b.y) - (double)(oa.y * ob.x - oa.x * ob.y);
-            pw += (double)(b.x * b.x + b.y * b.y) - (double)(oa.x * oa.x + oa.y * oa.y);
+    for (long long row = row0; row <= row1; row++) {
+        const long long n0 = row * 64;
+        const c32d xc = ld(x, n0 + lane, n);
+        const row_sums cur = scan_row(xc, xp, lane);
+        const int s48 = (lane + 16) & 63;
+        const float cr48 = __shfl(cur.sr, s48), ci48 = __shfl(cur.si, s48);
+        const float pr48 = __shfl(prev.sr, s48), pi48 = __shfl(prev.si, s48);
+        const float wr = lane >= 48 ? cur.sr - cr48 : cur.sr + (prev.tr - pr48);
+        const float wi = lane >= 48 ? cur.si - ci48 : cur.si + (prev.ti - pi48);
+        const float wp = cur.sp + (prev.tp - prev.sp);
+        float ac = sqrtf(wr * wr + wi * wi) / wp;
+        const long long i = n0 + lane;
+        if (i < a || i >= hi || !(ac > best)) ac = -1.0f;  // only a value above the running maximum sets the flag
+        // first lane holding the row's maximum
+        float m = ac;
+        for (int d = 32; d > 0; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
+        if (m > best) {
+            const unsigned long long who = __ballot(ac == m);
+            const int l = __ffsll((long long)who) - 1;
+            best = m;
+            at = n0 + l;
+            br = __shfl(wr, l);
+            bi = __shfl(wi, l);
         }
-        const float fr = (float)cr, fi = (float)ci;
-        const float ac = sqrtf(fr * fr + fi * fi) / (float)pw;
-        if (ac > best) {
-            best = ac;
-            at = i;
-            vr = fr;
-            vi = fi;
-        }
+        xp = xc;
+        prev = cur;
     }
+    vr = br;
+    vi = bi;
     return at >= lo ? at : -1;
 }
 
@@ -383,78 +394,89 @@ __global__ __launch_bounds__(64) void k_det_sync(const c32d *__restrict__ x, lon
                                                  float *__restrict__ out_rad, float *__restrict__ out_snr,
                                                  float *__restrict__ out_rssi, uint32_t *__restrict__ emitted)
 {
-    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long r = blockIdx.x;
     if (r >= nruns) return;
-    emitted[r] = 0;
+    const int lane = threadIdx.x;
+    if (lane == 0) emitted[r] = 0;
     const long long T = seen_at[r];
     if (T < 0) return;
+    __shared__ c32d s_x[SYNC_BUF];
+    __shared__ c32d s_pr[176];   // sig[i] * conj(sig[i+64])
+    __shared__ float s_mm[SYNC_BUF];  // |sig[i]|^2 as the reference forms it: abs * abs
+    __shared__ c32d s_c[64];
 
-    // ---- L-LTF autocorrelation over 111 positions, running sums exactly as lib/sync_impl.cc:139-171
-    const c32d *sig = x + T;
+    // ---- 2. L-LTF autocorrelation
+    for (int j = lane; j < SYNC_BUF; j += 64) s_x[j] = x[T + j];  // T + 240 <= n by construction
+    __syncthreads();
+    for (int j = lane; j < SYNC_BUF; j += 64) {
+        const c32d v = s_x[j];
+        const float m = cabs_ref(v.x, v.y);
+        s_mm[j] = m * m;
+        if (j < 176) {
+            const c32d w = s_x[j + 64];
+            c32d p;
+            p.x = v.x * w.x + v.y * w.y;  // a * conj(b): (ac+bd, bc-ad)
+            p.y = v.y * w.x - v.x * w.y;
+            s_pr[j] = p;
+        }
+    }
+    __syncthreads();
     float msr = 0.0f, msi = 0.0f, s1 = 0.0f, s2 = 0.0f;
     for (int i = 0; i < 64; i++) {
-        const c32d a = sig[i], b = sig[i + 64];
-        msr += a.x * b.x + a.y * b.y;  // a * conj(b): (ac+bd, bc-ad)
-        msi += a.y * b.x - a.x * b.y;
-        const float ma = cabs_ref(a.x, a.y), mb = cabs_ref(b.x, b.y);
-        s1 += ma * ma;
-        s2 += mb * mb;
+        const c32d p = s_pr[i];
+        msr += p.x;
+        msi += p.y;
+        s1 += s_mm[i];
+        s2 += s_mm[i + 64];
     }
-    float best = -1.0f, best_pwr = 0.0f;
-    int mx = 0;
-    // first pass: maximum (first occurrence); the values are recomputed in the shoulder search
-    {
-        float r_ = msr, i_ = msi, p1 = s1, p2 = s2;
-        for (int i = 0; i < SYNC_RES; i++) {
-            const float ac = cabs_ref(r_, i_) / sqrtf(p1) / sqrtf(p2);
-            if (i == 0 || ac > best) {
-                best = ac;
-                best_pwr = p1;
-                mx = i;
-            }
-            const c32d a = sig[i], b = sig[i + 64], c = sig[i + 128];
-            r_ -= a.x * b.x + a.y * b.y;
-            i_ -= a.y * b.x - a.x * b.y;
-            const float ma = cabs_ref(a.x, a.y), mb = cabs_ref(b.x, b.y), mc = cabs_ref(c.x, c.y);
-            p1 -= ma * ma;
-            p2 -= mb * mb;
-            r_ += b.x * c.x + b.y * c.y;
-            i_ += b.y * c.x - b.x * c.y;
-            p1 += mb * mb;
-            p2 += mc * mc;
+    // lane l keeps the sums at positions l and l + 64
+    float k_r[2] = {0.0f, 0.0f}, k_i[2] = {0.0f, 0.0f}, k_1[2] = {1.0f, 1.0f}, k_2[2] = {1.0f, 1.0f};
+#pragma unroll 1
+    for (int i = 0; i < SYNC_RES; i++) {
+        const bool mine = (i & 63) == lane;
+        const int h = i >> 6;
+        if (mine) {
+            if (h == 0) { k_r[0] = msr; k_i[0] = msi; k_1[0] = s1; k_2[0] = s2; }
+            else { k_r[1] = msr; k_i[1] = msi; k_1[1] = s1; k_2[1] = s2; }
         }
+        const c32d po = s_pr[i], pn = s_pr[i + 64];
+        const float m0 = s_mm[i], m1 = s_mm[i + 64], m2 = s_mm[i + 128];
+        msr -= po.x;
+        msi -= po.y;
+        s1 -= m0;
+        s2 -= m1;
+        msr += pn.x;
+        msi += pn.y;
+        s1 += m1;
+        s2 += m2;
     }
-    if (!((double)best > 0.5)) return;  // lib/sync_impl.cc:99
+    float acv[2];
+    acv[0] = cabs_ref(k_r[0], k_i[0]) / sqrtf(k_1[0]) / sqrtf(k_2[0]);
+    acv[1] = lane + 64 < SYNC_RES ? cabs_ref(k_r[1], k_i[1]) / sqrtf(k_1[1]) / sqrtf(k_2[1]) : -1.0f;
+    // std::max_element: the first maximum
+    float best = fmaxf(acv[0], acv[1]);
+    for (int d = 32; d > 0; d >>= 1) best = fmaxf(best, __shfl_xor(best, d));
+    const unsigned long long e0 = __ballot(acv[0] == best), e1 = __ballot(acv[1] == best);
+    const int mx = e0 ? __ffsll((long long)e0) - 1 : 64 + __ffsll((long long)e1) - 1;
+    if (!((double)best > 0.5)) return;  // lib/sync_impl.cc:99 (uniform)
     const float lim = (float)((double)best * 0.8);
+    const unsigned long long b0 = __ballot(acv[0] < lim), b1 = __ballot(lane + 64 < SYNC_RES && acv[1] < lim);
+    // l = last position <= mx below the limit (mx if none), rr = first position >= mx below it (mx if none)
     int l = mx, rr = mx;
     {
-        // second pass: l = last index <= mx below the limit, rr = first index >= mx below it
-        float r_ = msr, i_ = msi, p1 = s1, p2 = s2;
-        bool have_r = false;
-        for (int i = 0; i < SYNC_RES; i++) {
-            const float ac = cabs_ref(r_, i_) / sqrtf(p1) / sqrtf(p2);
-            if (i <= mx && ac < lim) l = i;
-            if (i >= mx && !have_r && ac < lim) {
-                rr = i;
-                have_r = true;
-            }
-            const c32d a = sig[i], b = sig[i + 64], c = sig[i + 128];
-            r_ -= a.x * b.x + a.y * b.y;
-            i_ -= a.y * b.x - a.x * b.y;
-            const float ma = cabs_ref(a.x, a.y), mb = cabs_ref(b.x, b.y), mc = cabs_ref(c.x, c.y);
-            p1 -= ma * ma;
-            p2 -= mb * mb;
-            r_ += b.x * c.x + b.y * c.y;
-            i_ += b.y * c.x - b.x * c.y;
-            p1 += mb * mb;
-            p2 += mc * mc;
-        }
+        const unsigned long long lo0 = mx >= 63 ? b0 : (b0 & ((2ull << mx) - 1ull));
+        const unsigned long long lo1 = mx >= 64 ? (b1 & ((2ull << (mx - 64)) - 1ull)) : 0ull;
+        if (lo1) l = 64 + 63 - __clzll((long long)lo1);
+        else if (lo0) l = 63 - __clzll((long long)lo0);
+        const unsigned long long hi0 = mx >= 64 ? 0ull : (b0 & ~((1ull << mx) - 1ull));
+        const unsigned long long hi1 = mx >= 64 ? (b1 & ~((1ull << (mx - 64)) - 1ull)) : b1;
+        if (hi0) rr = __ffsll((long long)hi0) - 1;
+        else if (hi1) rr = 64 + __ffsll((long long)hi1) - 1;
     }
     const int m = (l + rr) / 2;
+    const float best_pwr = mx < 64 ? __shfl(k_1[0], mx) : __shfl(k_1[1], mx - 64);
 
-    // ---- the conjugate average sync holds when it meets this trigger byte (lib/sync_impl.cc:85-88): the value at
-    // the last "new maximum" flag it scanned.  Flags inside the 111 items it skipped after an earlier trigger were
-    // never seen; then the value found for that earlier trigger is still in place.
+    // ---- 1. conjugate average
     float cvr = 0.0f, cvi = 0.0f;
     {
         long long run = r;
@@ -465,32 +487,40 @@ __global__ __launch_bounds__(64) void k_det_sync(const c32d *__restrict__ x, lon
             long long q = run;
             while (q + 1 < nruns && rise[q + 1] < t) q++;
             const long long hi = fall[q] < t ? fall[q] : t;
-            if (last_max_flag(x, n, rise[q], hi, lo, cvr, cvi) >= 0) break;
+            if (plateau_peak(x, n, rise[q], hi, lo, lane, cvr, cvi) >= 0) break;
             cvr = cvi = 0.0f;
             run = prev_seen[run];
         }
     }
 
-    // ---- CFO: coarse from the 16-lag average, fine from the two LTF halves (lib/sync_impl.cc:173-191)
+    // ---- 3. CFO: coarse from the 16-lag average, fine from the two LTF halves
     const float step_stf = atan2f(cvi, cvr) / 16.0f;
-    const c32d *ls = x + T + m;
-    float csr = 0.0f, csi = 0.0f;
-    for (int i = 0; i < 64; i++) {
-        const c32d a = ls[i], b = ls[i + 64];
-        const float ca = cosf(i * step_stf), sa = sinf(i * step_stf);
-        const float cb = cosf((i + 64) * step_stf), sb = sinf((i + 64) * step_stf);
+    {
+        const c32d a = s_x[m + lane], b = s_x[m + lane + 64];
+        const float ca = cosf(lane * step_stf), sa = sinf(lane * step_stf);
+        const float cb = cosf((lane + 64) * step_stf), sb = sinf((lane + 64) * step_stf);
         const float ar = a.x * ca - a.y * sa, ai = a.x * sa + a.y * ca;
         const float br = b.x * cb - b.y * sb, bi = b.x * sb + b.y * cb;
-        csr += ar * br + ai * bi;
-        csi += ai * br - ar * bi;
+        c32d p;
+        p.x = ar * br + ai * bi;
+        p.y = ai * br - ar * bi;
+        s_c[lane] = p;
+    }
+    __syncthreads();
+    float csr = 0.0f, csi = 0.0f;
+    for (int i = 0; i < 64; i++) {
+        csr += s_c[i].x;
+        csi += s_c[i].y;
     }
     const float step_ltf = atan2f(csi / 64.0f, csr / 64.0f) / 64.0f;
-    const double mxd = (double)best;
-    out_pos[r] = T + m;
-    out_rad[r] = step_stf + step_ltf;
-    out_snr[r] = (float)(10.0 * log10(mxd / (1.0 - mxd)));
-    out_rssi[r] = best_pwr / 64.0f;
-    emitted[r] = 1;
+    if (lane == 0) {
+        const double mxd = (double)best;
+        out_pos[r] = T + m;
+        out_rad[r] = step_stf + step_ltf;
+        out_snr[r] = (float)(10.0 * log10(mxd / (1.0 - mxd)));
+        out_rssi[r] = best_pwr / 64.0f;
+        emitted[r] = 1;
+    }
 }
 
 // -----------------------------------------------------------------------------------------
@@ -642,7 +672,7 @@ void launch_det_trigger_sync(const void *iq, long long n, const long long *rise,
     // a run that is not the head of a chain gets its entries from the head's walk; clear first for runs that
     // no walk reaches (none by construction, but the arrays are reused between calls)
     hipLaunchKernelGGL(k_det_trigger, dim3(nb), dim3(256), 0, s, rise, fall, nruns, n, seen_at, scan_lo, prev_seen);
-    hipLaunchKernelGGL(k_det_sync, dim3((unsigned)((nruns + 63) / 64)), dim3(64), 0, s, (const c32d *)iq, n, rise, fall,
+    hipLaunchKernelGGL(k_det_sync, dim3((unsigned)nruns), dim3(64), 0, s, (const c32d *)iq, n, rise, fall,
                        nruns, seen_at, scan_lo, prev_seen, pos, rad, snr, rssi, emitted);
     hipLaunchKernelGGL(k_det_flag_count, dim3(nb), dim3(256), 0, s, emitted, nruns, blk);
     hipLaunchKernelGGL(k_det_scan, dim3(1), dim3(1024), 0, s, blk, (uint32_t *)nullptr, nb, totals, 2);
