@@ -151,6 +151,7 @@ int run_decode_stages(gr80211_ctx *c, hipStream_t s, int n, bool from_iq, const 
     mark(c, 3, s);
     if (decode) {
         launch_clear_outputs(d_out_len, d_n_pdu, n, s);
+        if (from_iq && !d_iq1) launch_ndp_emit(d_iq0, d_desc, n, info, d_out, out_stride, d_out_len, d_n_pdu, s);
         if (tot.n_groups > 0) {
             if ((rc = ensure(c, c->dec, (size_t)(tot.dec_words + 128) * sizeof(uint32_t)))) return rc;
             if ((rc = ensure(c, c->bitsw, (size_t)(tot.bits_words + 64) * sizeof(uint32_t)))) return rc;

@@ -52,6 +52,8 @@ void launch_decode(const float *llr, const gr80211_frame_info *info, const int32
 #ifdef GR80211_TIMELINE
 int read_timeline(unsigned long long *dst, int n_groups);
 #endif
+void launch_ndp_emit(const void *iq0, const gr80211_frame_desc *desc, int n, const gr80211_frame_info *info, uint8_t *out,
+                     int out_stride, int32_t *out_len, int32_t *n_pdu, hipStream_t s);
 void launch_clear_outputs(int32_t *out_len, int32_t *n_pdu, int n, hipStream_t s);
 
 }  // namespace gr80211

@@ -432,12 +432,16 @@ __global__ __launch_bounds__(64) void k_preamble(const c32 *__restrict__ iq0, co
     // ---- HT / VHT: channel estimate (+ VHT-SIG-B) -----------------------------------------
     {
         const int fmt = s_ctl[4];
-        const int nss = s_m.nSS, nltf = s_m.nLTF;
-        if (nss > 2 || (nss == 2 && !two_ant)) {
+        const int nltf = s_m.nLTF;
+        // A two-stream VHT frame on one antenna is only followed as far as VHT-SIG-B, with the channel of the first
+        // VHT-LTF, to see whether it is a sounding NDP (lib/demod_impl.cc:393-409,452-455).
+        const bool sounding = s_m.nSS == 2 && !two_ant && fmt == GR80211_F_VHT;
+        if (s_m.nSS > 2 || (s_m.nSS == 2 && !two_ant && !sounding)) {
             if (lane == 0) s_ctl[0] = GR80211_ST_DROP_UNSUPPORTED;
             __syncthreads();
             goto finish;
         }
+        const int nss = sounding ? 1 : s_m.nSS;  // streams the equaliser separates
         const int off = pos + 80;
         c32 h[4], hi[4];
         c32 hn = mk(0.0f, 0.0f);
@@ -575,7 +579,12 @@ __global__ __launch_bounds__(64) void k_preamble(const c32 *__restrict__ iq0, co
                 parse_vhtb(s_bits, &s_m);
                 const ModS m = s_m;
                 if (m.len == 0 && m.nSym == 0) {
-                    s_ctl[0] = GR80211_ST_DROP_UNSUPPORTED;  // NDP
+                    // NDP: one antenna reports the raw VHT-LTF samples (lib/demod_impl.cc:238-249,265-271);
+                    // the two-antenna block requires len > 0 and drops it (lib/demod2_impl.cc:159)
+                    s_ctl[0] = two_ant ? GR80211_ST_DROP_LEN_CHECK : GR80211_ST_NDP;
+                    s_ctl[6] = pos + 80;
+                } else if (sounding) {
+                    s_ctl[0] = GR80211_ST_DROP_UNSUPPORTED;  // two streams of data on one antenna
                 } else if (!(m.len > 0 && m.len <= 4095 && m.nSS <= 2 &&
                              (nleg * 80) >= (m.nSym * m.nSymSamp + 160 + 80 + m.nLTF * 80 + 80))) {
                     s_ctl[0] = GR80211_ST_DROP_LEN_CHECK;
@@ -1527,6 +1536,49 @@ __global__ __launch_bounds__(64) void k_decode(const float *__restrict__ llr, co
 #endif
 }
 
+// =========================================================================================
+// k_ndp_emit: the channel message of a sounding NDP (lib/decode_impl.cc:100-121): type byte 20, length 1024,
+// then the 64 + 64 time samples of the two VHT-LTF FFT windows as `signal` forwards them, i.e. CFO-derotated
+// (lib/demod_impl.cc:397-398: copies of sig1[8..72) and sig1[88..152) of the samples after VHT-STF).
+// One wave per frame, lane = sample of each window.
+// =========================================================================================
+__global__ __launch_bounds__(256) void k_ndp_emit(const c32 *__restrict__ iq0, const gr80211_frame_desc *__restrict__ descs,
+                                                  int n, const gr80211_frame_info *__restrict__ info,
+                                                  uint8_t *__restrict__ out, int out_stride, int32_t *__restrict__ out_len,
+                                                  int32_t *__restrict__ n_pdu)
+{
+    const int f = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (f >= n) return;
+    const gr80211_frame_info fi = info[f];
+    if (fi.status != GR80211_ST_NDP) return;
+    constexpr int NBYTES = 128 * 8;
+    if (out_stride < NBYTES + 3) return;  // no room: nothing is published, as for any PDU that does not fit
+    const int lane = threadIdx.x & 63;
+    const gr80211_frame_desc d = descs[f];
+    const c32 *in0 = iq0 + d.sync_off;
+    int nvalid = fi.nsamp;
+    if (nvalid > (int)d.n_avail - 224) nvalid = (int)d.n_avail - 224;
+    uint8_t *o = out + (size_t)f * out_stride;
+    for (int w = 0; w < 2; w++) {
+        const c32 v = load_samp(in0, fi.data_off + w * 80 + SHIFT + lane, nvalid, d.rad);
+        // byte-wise: the slot is only byte aligned (3-byte header)
+        const uint32_t re = __float_as_uint(v.x), im = __float_as_uint(v.y);
+        uint8_t *p = o + 3 + (w * 64 + lane) * 8;
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            p[b] = (uint8_t)(re >> (8 * b));
+            p[4 + b] = (uint8_t)(im >> (8 * b));
+        }
+    }
+    if (lane == 0) {
+        o[0] = 20;  // C8P_F_VHT_CHAN
+        o[1] = (uint8_t)(NBYTES % 256);
+        o[2] = (uint8_t)(NBYTES / 256);
+        out_len[f] = NBYTES + 3;
+        n_pdu[f] = 1;
+    }
+}
+
 __global__ void k_clear_outputs(int32_t *a, int32_t *b, int n)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1584,6 +1636,12 @@ void launch_decode(const float *llr, const gr80211_frame_info *info, const int32
 {
     hipLaunchKernelGGL(k_decode, dim3(n_groups), dim3(64), 0, s, llr, info, slot_frame, groups, n_groups, dec, bitsw,
                        out, out_stride, out_len, n_pdu, bits_out, bits_stride);
+}
+void launch_ndp_emit(const void *iq0, const gr80211_frame_desc *desc, int n, const gr80211_frame_info *info, uint8_t *out,
+                     int out_stride, int32_t *out_len, int32_t *n_pdu, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_ndp_emit, dim3((n + 3) / 4), dim3(256), 0, s, (const c32 *)iq0, desc, n, info, out, out_stride,
+                       out_len, n_pdu);
 }
 void launch_clear_outputs(int32_t *out_len, int32_t *n_pdu, int n, hipStream_t s)
 {

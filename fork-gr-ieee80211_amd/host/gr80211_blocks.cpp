@@ -11,6 +11,7 @@ namespace host {
 namespace {
 
 const int LSIG_SPAN = 224;       // samples from the trigger to the end of L-SIG (lib/signal_impl.cc:110,154)
+const int F_VHT_CHAN = 20;       // format byte of the sounding channel message (lib/cloud80211phy.h:40)
 const int LSIG_FAIL_SKIP = 80;   // samples dropped after a failed L-SIG check (lib/signal_impl.cc:156-160)
 const int OUT_STRIDE = 4352;     // room for the PDUs of one frame: 4095 bytes + headers of a few subframes
 const long DEFAULT_TAG = 99999;  // value `decode` assumes for a missing tag (lib/decode_impl.cc:77-83)
@@ -153,7 +154,7 @@ int decode::general_work(int, gr_vector_int &ninput_items, gr_vector_const_void_
                 pdu_t m;
                 const int nbytes = (int)sizeof(float) * 256;
                 m.blob.assign(nbytes + 3, 0);
-                m.blob[0] = 20;  // C8P_F_VHT_CHAN
+                m.blob[0] = F_VHT_CHAN;
                 m.blob[1] = (uint8_t)(nbytes % 256);
                 m.blob[2] = (uint8_t)(nbytes / 256);
                 if (ch) {
@@ -248,11 +249,12 @@ bool decode::run_batch()
         while (at + 4 <= len[i]) {
             const int L = p[at + 1] | (p[at + 2] << 8);
             pdu_t m;
-            m.blob.assign(p + at, p + at + L + 4);
-            m.len = L + 4;
+            const int rec = L + (p[at] == F_VHT_CHAN ? 3 : 4);  // a channel message has no trailing mcs byte
+            m.blob.assign(p + at, p + at + rec);
+            m.len = rec;
             message_port_pub("out", m);
             d_nPdu++;
-            at += L + 4;
+            at += rec;
         }
     }
     d_llr.clear();
@@ -445,11 +447,12 @@ bool rx::process(bool final)
             while (at + 4 <= len[i]) {
                 const int L = p[at + 1] | (p[at + 2] << 8);
                 pdu_t m;
-                m.blob.assign(p + at, p + at + L + 4);
-                m.len = L + 4;
+                const int rec = L + (p[at] == F_VHT_CHAN ? 3 : 4);  // a channel message has no trailing mcs byte
+                m.blob.assign(p + at, p + at + rec);
+                m.len = rec;
                 message_port_pub("out", m);
                 d_nPdu++;
-                at += L + 4;
+                at += rec;
             }
         }
     }
@@ -530,11 +533,12 @@ bool capture_rx::flush()
         while (at + 4 <= len[i]) {
             const int L = p[at + 1] | (p[at + 2] << 8);
             pdu_t m;
-            m.blob.assign(p + at, p + at + L + 4);
-            m.len = L + 4;
+            const int rec = L + (p[at] == F_VHT_CHAN ? 3 : 4);  // a channel message has no trailing mcs byte
+            m.blob.assign(p + at, p + at + rec);
+            m.len = rec;
             message_port_pub("out", m);
             d_nPdu++;
-            at += L + 4;
+            at += rec;
         }
     }
     for (int a = 0; a < d_nrx; a++) d_hold[a].clear();

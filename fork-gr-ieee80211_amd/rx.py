@@ -13,7 +13,9 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GR80211_RX_LIB", os.path.join(_HERE, "libgr80211_rx.so"))  # override: A/B builds
 
-ST_NAMES = {0: "ok", 1: "drop_lsig", 2: "drop_len_check", 3: "drop_unsupported", 4: "drop_decode_limit"}
+ST_NAMES = {0: "ok", 1: "drop_lsig", 2: "drop_len_check", 3: "drop_unsupported", 4: "drop_decode_limit", 5: "ndp"}
+ST_NAMES_INV = {v: k for k, v in ST_NAMES.items()}
+F_VHT_CHAN = 20  # format byte of a sounding channel message (C8P_F_VHT_CHAN, lib/cloud80211phy.h)
 FLAG_DESC_ON_DEVICE = 1
 
 
@@ -105,6 +107,10 @@ def split_pdus(blob):
     p = 0
     while p + 4 <= len(blob):
         ln = blob[p + 1] | (blob[p + 2] << 8)
+        if blob[p] == F_VHT_CHAN:  # 128 complex64 samples, no trailing mcs byte (lib/decode_impl.cc:105-120)
+            out.append(dict(format=F_VHT_CHAN, mcs=None, mpdu=bytes(blob[p + 3:p + 3 + ln])))
+            p += ln + 3
+            continue
         out.append(dict(format=int(blob[p]), mcs=int(blob[p + 3 + ln]), mpdu=bytes(blob[p + 3:p + 3 + ln])))
         p += ln + 4
     return out

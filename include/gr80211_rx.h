@@ -42,6 +42,9 @@ extern "C" {
 #define GR80211_ST_DROP_LEN_CHECK 2   /* demod: HT/VHT length sanity failed (lib/demod_impl.cc:159,186) */
 #define GR80211_ST_DROP_UNSUPPORTED 3 /* nSS>2, MU group id, NDP, VHT MCS>9 */
 #define GR80211_ST_DROP_DECODE_LIMIT 4/* decode: len>4095 or trellis>32782 (lib/decode_impl.cc:93) */
+#define GR80211_ST_NDP 5              /* VHT sounding NDP seen by the one-antenna chain: no soft bits; its PDU is the
+                                         channel message [20][len lo][len hi][128 complex64 raw VHT-LTF samples]
+                                         (lib/demod_impl.cc:238-249,397-398, lib/decode_impl.cc:100-121) */
 
 #define GR80211_MAX_TRELLIS 32782 /* DECODE_T_MAX, lib/decode_impl.h:36 */
 #define GR80211_MAX_PSDU 4095     /* DECODE_B_MAX, lib/decode_impl.h:35 */

@@ -32,6 +32,7 @@ class Frame(C.Structure):
         ("sssnr0", C.c_float), ("sssnr1", C.c_float),
         ("sig_bits", C.c_uint8 * 48),
         ("sigb_bits", C.c_uint8 * 26),
+        ("mu2x1chan", C.c_float * 256),
     ]
 
 
@@ -116,6 +117,10 @@ def split_pdus(blob):
     p = 0
     while p + 4 <= len(blob):
         ln = blob[p + 1] | (blob[p + 2] << 8)
+        if blob[p] == 20:  # sounding channel message: no trailing mcs byte (decode_impl.cc:105-120)
+            out.append(dict(format=20, mcs=None, mpdu=bytes(blob[p + 3:p + 3 + ln])))
+            p += ln + 3
+            continue
         out.append(dict(format=int(blob[p]), mcs=int(blob[p + 3 + ln]), mpdu=bytes(blob[p + 3:p + 3 + ln])))
         p += ln + 4
     return out

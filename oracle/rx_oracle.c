@@ -680,13 +680,13 @@ static void nl2_update(const src_t *s, int off, chan_t *c, int vht, cf *q0, cf *
 static void nl_chan_est(const src_t *s, int off, const orc_mod_t *m, int two_ant, chan_t *c)
 {
     cf F1[64], F2[64], F12[64], F22[64];
-    if (m->nSS == 1) {
+    if (m->nSS == 1 || !two_ant) {
+        /* one stream, or channel sounding seen by one antenna: the first LTF only (demod_impl.cc:380-409) */
         fft_at(s, 0, off, F1);
         for (int i = 0; i < 64; i++)
             if (nl_used(i)) c->h[i][0] = F1[i] / T_LTF_NL[i];
         return;
     }
-    if (!two_ant) return;
     fft_at(s, 0, off, F1);
     fft_at(s, 1, off, F2);
     fft_at(s, 0, off + 80, F12);
@@ -830,11 +830,27 @@ int orc_demod(const float *in0_ri, const float *in1_ri, int navail, float rad, o
     int nleg = (f->lsig_len * 8 + 22 + 23) / 24;
     if (fmt == ORC_F_VHT) {
         /* DEMOD_S_VHT, lib/demod_impl.cc:150-178 / lib/demod2_impl.cc:150-177 */
-        if (m->nSS > 2 || (m->nSS == 2 && !two_ant)) { f->status = ORC_DROP_UNSUPPORTED; goto done; }
+        if (m->nSS > 2) { f->status = ORC_DROP_UNSUPPORTED; goto done; }
+        /* two streams on one antenna: followed up to VHT-SIG-B to see whether it is a sounding NDP
+         * (demod_impl.cc:393-409,452-455); two streams of data on one antenna have no defined result */
+        int sounding = (m->nSS == 2 && !two_ant);
         nl_chan_est(&s, pos + 80, m, two_ant, c);
         vht_sigb(&s, pos + 80 + m->nLTF * 80, m, two_ant, c, f);
         parse_vhtb(f->sigb_bits, m);
-        if (m->len == 0 && m->nSym == 0) { f->status = ORC_DROP_UNSUPPORTED; goto done; } /* NDP */
+        if (m->len == 0 && m->nSym == 0) {
+            if (two_ant) { f->status = ORC_DROP_LEN_CHECK; goto done; } /* demod2 requires len > 0 (demod2_impl.cc:159) */
+            /* NDP on one antenna: raw samples of the two LTF windows (demod_impl.cc:397-398,238-249) */
+            for (int i = 0; i < 64; i++) {
+                cf a = samp(&s, 0, pos + 80 + SHIFT + i), b = samp(&s, 0, pos + 80 + 80 + SHIFT + i);
+                f->mu2x1chan[2 * i] = crealf(a);
+                f->mu2x1chan[2 * i + 1] = cimagf(a);
+                f->mu2x1chan[128 + 2 * i] = crealf(b);
+                f->mu2x1chan[128 + 2 * i + 1] = cimagf(b);
+            }
+            f->status = ORC_NDP;
+            goto done;
+        }
+        if (sounding) { f->status = ORC_DROP_UNSUPPORTED; goto done; }
         if (!(m->len > 0 && m->len <= 4095 && m->nSS <= 2 &&
               (nleg * 80) >= (m->nSym * m->nSymSamp + 160 + 80 + m->nLTF * 80 + 80))) {
             f->status = ORC_DROP_LEN_CHECK;
@@ -1048,7 +1064,18 @@ int orc_rx_frame(const float *in0_ri, const float *in1_ri, int navail, float rad
     *out_len = 0;
     *n_pdu = 0;
     if (orc_signal(in0_ri, navail, rad, f) != ORC_OK) return f->status;
-    if (orc_demod(in0_ri, in1_ri, navail, rad, f, llr, llr_cap) != ORC_OK) return f->status;
+    if (orc_demod(in0_ri, in1_ri, navail, rad, f, llr, llr_cap) != ORC_OK) {
+        if (f->status == ORC_NDP && out_cap >= 1027) {
+            /* decode republishes the channel as a message of its own (decode_impl.cc:100-121) */
+            out[0] = 20; /* C8P_F_VHT_CHAN */
+            out[1] = (uint8_t)(1024 % 256);
+            out[2] = (uint8_t)(1024 / 256);
+            memcpy(out + 3, f->mu2x1chan, 1024);
+            *out_len = 1027;
+            *n_pdu = 1;
+        }
+        return f->status;
+    }
     if (f->m.len > ORC_MAX_PSDU || f->trellis > ORC_MAX_TRELLIS) {
         f->status = ORC_DROP_DECODE_LIMIT;
         return f->status;

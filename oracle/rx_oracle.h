@@ -31,7 +31,9 @@ enum {
     ORC_DROP_LSIG = 1,       /* L-SIG parity/rate/length check failed (signal_impl.cc:156-160) */
     ORC_DROP_LEN_CHECK = 2,  /* HT/VHT length vs L-SIG duration sanity failed (demod_impl.cc:159,186) */
     ORC_DROP_UNSUPPORTED = 3,/* nSS>2, MU-MIMO group id, NDP, invalid MCS: outside this build's scope */
-    ORC_DROP_DECODE_LIMIT = 4/* len>4095 or trellis>32782 (decode_impl.cc:93) */
+    ORC_DROP_DECODE_LIMIT = 4,/* len>4095 or trellis>32782 (decode_impl.cc:93) */
+    ORC_NDP = 5              /* VHT sounding NDP on the one-antenna chain: channel message instead of a PSDU
+                                (demod_impl.cc:238-249,397-398, decode_impl.cc:100-121) */
 };
 
 /* Modulation descriptor: the fields of c8p_mod (lib/cloud80211phy.h:58-98) the path uses. */
@@ -53,6 +55,7 @@ typedef struct {
     float sssnr0, sssnr1;
     uint8_t sig_bits[48]; /* decoded HT-SIG or VHT-SIG-A bits */
     uint8_t sigb_bits[26];
+    float mu2x1chan[256]; /* NDP: the 64 + 64 raw VHT-LTF samples, re/im interleaved (demod_impl.cc:397-398) */
 } orc_frame_t;
 
 void orc_init(void);

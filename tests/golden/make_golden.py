@@ -97,6 +97,22 @@ def make_frames():
         print("frame", name, rx.shape)
 
 
+def make_ndp():
+    """VHT sounding NDP (two space-time streams, no data field) as one RX antenna sees it through H22's first
+    row.  The expected message is derived in the tests from the IQ itself (the channel message carries raw
+    VHT-LTF window samples), so the fixture is the waveform only."""
+    phy = phy80211.phy80211(ifDebug=False)
+    with contextlib.redirect_stdout(io.StringIO()):
+        phy.genFromAmpdu(b"", p8h.modulation(p8h.F.VHT, 0, p8h.BW.BW20, 2, False), vhtPartialAid=0, vhtGroupId=0)
+        ss = phy.genFinalSig(multiplier=12.0 * np.sqrt(2), cfoHz=0.0, num=1, gap=True, gapLen=GAP)
+    tx = np.array(ss, dtype=np.complex128)
+    np.savez_compressed(
+        os.path.join(HERE, "ndp_vht_2sts.npz"),
+        iq=(H22 @ tx).astype(np.complex64),
+        sync_idx=np.int32(GAP + 160 + 16), rad=np.float32(0.0))
+    print("ndp", tx.shape)
+
+
 def make_viterbi():
     """Integer-LLR Viterbi vectors from the reference's Python decoder (ties included)."""
     rng = np.random.RandomState(7)
@@ -139,3 +155,4 @@ if __name__ == "__main__":
     copy_ref_fixtures()
     make_viterbi()
     make_frames()
+    make_ndp()

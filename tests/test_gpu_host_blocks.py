@@ -168,3 +168,21 @@ def test_capture_block_raw_stream(tmp_path, oracle):
     assert got == want
     assert [p[3:-1] for p in got] == [f["mpdu"] for f in frames]
     assert "frames=%d " % model_chain.dealt_with in stat + " ", stat
+
+
+def test_rx_block_publishes_ndp_channel(tmp_path, oracle):
+    """A sounding NDP in the stream: the block publishes the 1027-byte channel message (no mcs byte) between the
+    data frames' PDUs."""
+    from util import golden_ndp
+    g = golden_ndp()
+    frames = [f for f in golden_frames() if f["nss"] == 1][:2]
+    parts = [frames[0]["iq"][0], g["iq"][0], frames[1]["iq"][0], np.zeros(300, np.complex64)]
+    at = np.cumsum([0] + [len(p) for p in parts])
+    triggers = [(int(at[0]) + frames[0]["sync_idx"], frames[0]["rad"]), (int(at[1]) + g["sync_idx"], 0.0),
+                (int(at[2]) + frames[1]["sync_idx"], frames[1]["rad"])]
+    iq0 = np.concatenate(parts).astype(np.complex64)
+    want, n_frames = model_chain(oracle, iq0, None, triggers)
+    assert n_frames == 3 and [len(w) for w in want][1] == 1027 and want[1][0] == 20
+    tf, files = write_stream(tmp_path, iq0, None, triggers)
+    got, stat = run_pump(["rx", 1, 1500, 8, tf] + files)
+    assert got == want

@@ -215,3 +215,40 @@ def test_full_size_batch_roundtrip(pkg, rxctx):
     for i in (0, 1, 63, 64, 127, 199):
         got = rxctx.pdus_of(res, i)
         assert got[0]["mpdu"] == uniq[i % 6][1]
+
+
+def test_vht_sounding_ndp(pkg, rxctx, oracle):
+    """VHT NDP with two space-time streams on one antenna: no data field, the path publishes the raw samples of
+    the two VHT-LTF windows as a channel message (lib/demod_impl.cc:393-409,238-271, lib/decode_impl.cc:100-121).
+    Seen by the two-antenna path the same frame fails demod2's length check and is dropped."""
+    import torch
+    from util import golden_ndp
+    g = golden_ndp()
+    rng = np.random.default_rng(31)
+    vht = [f for f in golden_frames() if f["name"] == "vht_mcs4_200"][0]
+    noisy = awgn(g["iq"], 30.0, rng).astype(np.complex64)
+    frames = [([g["iq"][0]], g["sync_idx"]), ([vht["iq"][0]], vht["sync_idx"]), ([noisy[0]], g["sync_idx"])]
+    r = run_rx(pkg, rxctx, oracle, frames, check_llr=False)
+    s = g["sync_idx"]
+    for k, src in ((0, g["iq"][0]), (2, noisy[0])):
+        assert r[k]["status"] == pkg.rx.ST_NAMES_INV["ndp"] and r[k]["n_pdu"] == 1
+        want = bytes([20, 0, 4]) + src[s + 472:s + 536].tobytes() + src[s + 552:s + 616].tobytes()
+        assert r[k]["blob"] == want
+    assert [p["mpdu"] for p in r[1]["pdus"]] == [vht["mpdu"]]
+    # two antennas: dropped, like the reference's demod2
+    r2 = run_rx(pkg, rxctx, oracle, [([g["iq"][0], g["iq"][1]], s)], check_llr=False)
+    assert r2[0]["status"] == 2 and r2[0]["n_pdu"] == 0
+
+    # with a frequency offset the message holds derotated samples: float work, compared to tolerance
+    cfo = 150e3
+    rot = (g["iq"][0] * np.exp(1j * 2 * np.pi * cfo / 20e6 * np.arange(g["iq"].shape[1]))).astype(np.complex64)
+    rad = np.float32(-2 * np.pi * cfo / 20e6)
+    iq0, _, sync, navail = build_arena([([rot], s)])
+    res = rxctx.rx_batch(torch.from_numpy(iq0).cuda(), None, rxctx.make_desc(sync, navail, rad=np.array([rad], np.float32)), 1)
+    rxctx.sync()
+    ref = oracle.rx_frame(iq0[: int(sync[0]) + int(navail[0])], None, int(sync[0]), float(rad))
+    got = bytes(res["out"][0, : int(res["out_len"][0].item())].cpu().numpy())
+    assert ref["status"] == 5 and len(got) == 1027 and got[:3] == ref["blob"][:3]
+    a = np.frombuffer(got[3:], np.float32)
+    b = np.frombuffer(ref["blob"][3:], np.float32)
+    assert np.all(np.abs(a - b) <= 1e-5 * np.abs(b).max())

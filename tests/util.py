@@ -20,6 +20,11 @@ def golden_frames():
     return out
 
 
+def golden_ndp():
+    z = np.load(os.path.join(GOLDEN, "ndp_vht_2sts.npz"))
+    return dict(iq=z["iq"], sync_idx=int(z["sync_idx"]), rad=float(z["rad"]))
+
+
 def ref_fixture_mpdu():
     with open(os.path.join(GOLDEN, "ref_fixture_mpdu.hex")) as fh:
         return bytes.fromhex(fh.read().strip())
@@ -67,7 +72,8 @@ ST_DROP_LSIG = 1
 
 def blob_of(p):
     n = len(p["mpdu"])
-    return bytes([p["format"], n % 256, n // 256]) + p["mpdu"] + bytes([p["mcs"]])
+    tail = b"" if p["mcs"] is None else bytes([p["mcs"]])
+    return bytes([p["format"], n % 256, n // 256]) + p["mpdu"] + tail
 
 
 def model_chain(oracle, iq0, iq1, triggers):
