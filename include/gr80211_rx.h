@@ -40,7 +40,7 @@ extern "C" {
 #define GR80211_ST_OK 0
 #define GR80211_ST_DROP_LSIG 1        /* signal: L-SIG check failed (lib/signal_impl.cc:156-160) */
 #define GR80211_ST_DROP_LEN_CHECK 2   /* demod: HT/VHT length sanity failed (lib/demod_impl.cc:159,186) */
-#define GR80211_ST_DROP_UNSUPPORTED 3 /* nSS>2, MU group id, NDP, VHT MCS>9 */
+#define GR80211_ST_DROP_UNSUPPORTED 3 /* nSS>2, MU group id, VHT MCS>9, two data streams on one antenna */
 #define GR80211_ST_DROP_DECODE_LIMIT 4/* decode: len>4095 or trellis>32782 (lib/decode_impl.cc:93) */
 #define GR80211_ST_NDP 5              /* VHT sounding NDP seen by the one-antenna chain: no soft bits; its PDU is the
                                          channel message [20][len lo][len hi][128 complex64 raw VHT-LTF samples]
