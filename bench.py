@@ -275,6 +275,12 @@ def main():
                                    "not by HBM; it also reads the materialised soft bits and writes/reads the "
                                    "survivor words, which the per-frame figure (IQ in + PSDU out) does not count",
                            "acs_state_updates_per_s": 64.0 * steps_per_frame * n / (dec_ms * 1e-3)}
+        # VALU issue, the resource that does bound k_decode: one wave instruction updates one state of 64
+        # frames; the add/add/sub/max/alignbit mix costs 14.6 SIMD-cycles per wave-wide state update at the
+        # instruction rates measured on this chip (tools/ubench), on 1024 SIMDs at 2.4 GHz
+        wave_updates = 64.0 * steps_per_frame * ((n + 63) // 64)
+        cyc = 1024 * 2.4e9 * dec_ms * 1e-3 / wave_updates
+        res["roofline"]["valu_issue"] = {"simd_cycles_per_wave_state_update": cyc, "floor": 14.6, "frac": 14.6 / cyc}
     if rank == 0 and world == 1 and args.detect:
         # raw capture in: frame detection (presiso -> trigger -> sync) finds the frames, `signal`'s trigger search
         # picks the ones it deals with, then the same RX kernels run; reported beside the headline, which starts

@@ -7,6 +7,7 @@
 
 #include "detect_kernels.h"
 #include "rx_kernels.h"
+#include "tx_kernels.h"
 
 using namespace gr80211;
 
@@ -27,6 +28,7 @@ struct gr80211_ctx {
     Buf desc, ddesc, info, chan1, chan2, llr, slot_frame, groups, dec, bitsw, totals_d, sched_ws, blk_llr;
     // frame detection
     Buf det_mask, det_blk, det_runs, det_rec, det_totals_d, cap_desc, cap_ws;
+    Buf tx_desc;
     uint32_t *det_totals_h = nullptr;  // pinned
     SchedTotals *totals_h = nullptr;  // pinned
     bool profiling = false;
@@ -279,7 +281,7 @@ int gr80211_create(gr80211_ctx **out, int device)
     {
         std::lock_guard<std::mutex> lk(g_upload_mutex);
         if (!g_uploaded[device]) {
-            if (upload_tables(tables()) != 0) {
+            if (upload_tables(tables()) != 0 || upload_tx_tables(tables()) != 0) {
                 delete c;
                 return GR80211_ERR_HIP;
             }
@@ -315,7 +317,7 @@ void gr80211_destroy(gr80211_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (Buf *b : {&c->desc, &c->ddesc, &c->info, &c->chan1, &c->chan2, &c->llr, &c->slot_frame, &c->groups, &c->dec,
                    &c->bitsw, &c->totals_d, &c->sched_ws, &c->blk_llr, &c->det_mask, &c->det_blk, &c->det_runs,
-                   &c->det_rec, &c->det_totals_d, &c->cap_desc, &c->cap_ws})
+                   &c->det_rec, &c->det_totals_d, &c->cap_desc, &c->cap_ws, &c->tx_desc})
         release(*b);
     if (c->totals_h) (void)hipHostFree(c->totals_h);
     if (c->det_totals_h) (void)hipHostFree(c->det_totals_h);
@@ -495,6 +497,29 @@ int gr80211_decode_batch(gr80211_ctx *c, const float *d_llr, uint64_t llr_floats
                            d_bits, bits_stride, true, nullptr, nullptr);
     if (rc) return rc;
     return finish_timing(c, s);
+}
+
+int gr80211_tx_samples(int format, int mcs, int nss, int psdu_len)
+{
+    TxMod m;
+    return tx_mod(format, mcs, nss, psdu_len, m) ? m.nsamp : -1;
+}
+
+int gr80211_tx_batch(gr80211_ctx *c, const uint8_t *d_psdu, uint64_t psdu_bytes, const gr80211_tx_desc *desc, int n,
+                     unsigned flags, void *d_iq0, void *d_iq1, uint64_t arena_len, int32_t *d_n_samples, void *stream)
+{
+    if (!c) return GR80211_ERR_ARG;
+    if (n == 0) return GR80211_OK;
+    if (!d_psdu || !desc || n < 0 || !d_iq0) return fail(c, GR80211_ERR_ARG, "gr80211_tx_batch: bad argument");
+    if (n > (1 << 20)) return fail(c, GR80211_ERR_ARG, "gr80211_tx_batch: at most 1048576 frames per call");
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = pick(c, stream);
+    const void *dd = nullptr;
+    int rc = stage_desc(c, s, desc, (size_t)n * sizeof(gr80211_tx_desc), flags, c->tx_desc, &dd);
+    if (rc) return rc;
+    launch_tx(d_psdu, psdu_bytes, (const gr80211_tx_desc *)dd, n, d_iq0, d_iq1, arena_len, d_n_samples, s);
+    HIP_TRY(c, hipGetLastError());
+    return GR80211_OK;
 }
 
 void *gr80211_dev_alloc(gr80211_ctx *c, size_t bytes)

@@ -50,6 +50,9 @@ DEC_DESC_DTYPE = np.dtype([("llr_off", "<i8"), ("n_llr", "<i4"), ("format", "<i4
                            ("cr", "<i4"), ("mcs", "<i4"), ("ampdu", "<i4"), ("trellis", "<i4"),
                            ("reserved", "<i4")])
 
+TX_DESC_DTYPE = np.dtype([("out_off", "<u8"), ("psdu_off", "<u4"), ("psdu_len", "<i4"), ("format", "<i4"),
+                          ("mcs", "<i4"), ("nss", "<i4"), ("scrambler", "<i4"), ("scale", "<f4"), ("cfo_rad", "<f4")])
+assert TX_DESC_DTYPE.itemsize == 40
 assert FRAME_DESC_DTYPE.itemsize == C.sizeof(FrameDesc) == 32
 assert FRAME_INFO_DTYPE.itemsize == C.sizeof(FrameInfo) == 112
 assert DEC_DESC_DTYPE.itemsize == C.sizeof(DecDesc) == 40
@@ -58,7 +61,7 @@ EXPORTS = [
     "gr80211_create", "gr80211_destroy", "gr80211_last_error", "gr80211_sync", "gr80211_rx_batch", "gr80211_signal_batch", "gr80211_detect", "gr80211_rx_capture",
     "gr80211_demod_batch", "gr80211_decode_batch", "gr80211_dev_alloc", "gr80211_dev_free",
     "gr80211_copy_h2d", "gr80211_copy_d2h", "gr80211_set_profiling", "gr80211_last_timing",
-    "gr80211_version", "gr80211_table_checksum",
+    "gr80211_version", "gr80211_table_checksum", "gr80211_tx_samples", "gr80211_tx_batch",
 ]
 
 _lib = None
@@ -95,6 +98,8 @@ def load_library():
     L.gr80211_copy_d2h.argtypes = [vp, vp, vp, C.c_size_t, vp]
     L.gr80211_set_profiling.argtypes = [vp, C.c_int]
     L.gr80211_last_timing.argtypes = [vp, C.POINTER(C.c_float), C.c_int]
+    L.gr80211_tx_samples.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
+    L.gr80211_tx_batch.argtypes = [vp, vp, C.c_uint64, vp, C.c_int, C.c_uint, vp, vp, C.c_uint64, vp, vp]
     L.gr80211_version.restype = C.c_char_p
     L.gr80211_table_checksum.restype = C.c_uint32
     _lib = L
@@ -307,6 +312,35 @@ class RxContext:
             bits_stride if bits is not None else 0, self._stream())
         self._check(rc, "gr80211_decode_batch")
         return dict(out=out, out_len=out_len, n_pdu=n_pdu, bits=bits, _keep=keep)
+
+    # -- transmitter ---------------------------------------------------------------------
+    @staticmethod
+    def make_tx_desc(n):
+        d = np.zeros(n, dtype=TX_DESC_DTYPE)
+        d["nss"] = 1
+        d["scrambler"] = 93
+        d["scale"] = 1.0
+        return d
+
+    def tx_samples(self, fmt, mcs, nss, psdu_len):
+        return int(self.lib.gr80211_tx_samples(int(fmt), int(mcs), int(nss), int(psdu_len)))
+
+    def tx_batch(self, psdu, desc, n_frames, iq0, iq1=None):
+        """PSDU bytes (uint8 CUDA tensor) -> frames written into the complex64 CUDA arena(s) iq0 / iq1 at each
+        descriptor's out_off.  Returns the int32 CUDA tensor of per-frame sample counts (-1 = rejected)."""
+        t = self.torch
+        assert psdu.is_cuda and psdu.dtype == t.uint8 and psdu.is_contiguous()
+        assert iq0.is_cuda and iq0.dtype == t.complex64 and iq0.is_contiguous()
+        if iq1 is not None:
+            assert iq1.is_cuda and iq1.dtype == t.complex64 and iq1.numel() == iq0.numel()
+        ns = t.empty(max(n_frames, 1), dtype=t.int32, device=self.dev)
+        dp, flags, keep = self._desc_arg(desc)
+        rc = self.lib.gr80211_tx_batch(
+            self.h, C.c_void_p(psdu.data_ptr()), psdu.numel(), dp, n_frames, flags, C.c_void_p(iq0.data_ptr()),
+            C.c_void_p(iq1.data_ptr()) if iq1 is not None else None, iq0.numel(), C.c_void_p(ns.data_ptr()),
+            self._stream())
+        self._check(rc, "gr80211_tx_batch")
+        return ns[:n_frames]
 
     @staticmethod
     def pdus_of(res, i):

@@ -97,6 +97,24 @@ typedef struct {
 
 #define GR80211_FLAG_DESC_ON_DEVICE 1u /* the descriptor array argument is a device pointer */
 
+/*
+ * One frame to transmit: what the reference's Python generator takes in
+ * phy80211.genFromMpdu(mpdu, modulation(format, mcs, bw20, nSTS, shortGi=False)) / genFromAmpdu(ampdu, ...)
+ * (tools/phy80211.py:80-181) and genFinalSig(multiplier, cfoHz, ...) (tools/phy80211.py:1077-1094).
+ */
+typedef struct {
+    uint64_t out_off;  /* sample index in the output arena(s) where the frame (its L-STF) starts */
+    uint32_t psdu_off; /* byte offset of the PSDU in d_psdu: the MPDU (legacy, HT) or the A-MPDU with its
+                          delimiters (VHT), FCS included */
+    int32_t psdu_len;  /* bytes, 1..4095 (VHT: APEP length; padding to the symbol boundary is added) */
+    int32_t format;    /* GR80211_F_* */
+    int32_t mcs;       /* legacy 0..7, HT 0..15 (8..15 = two streams), VHT 0..8 */
+    int32_t nss;       /* VHT: 1 or 2 space-time streams; ignored otherwise */
+    int32_t scrambler; /* initial scrambler state 1..127 (the reference generator uses 93) */
+    float scale;       /* genFinalSig's multiplier */
+    float cfo_rad;     /* sample i of the frame is rotated by exp(j*i*cfo_rad): genFinalSig's cfoHz*2*pi/20e6 */
+} gr80211_tx_desc; /* 40 bytes */
+
 /* Library/device set-up.  device = HIP device ordinal. */
 int gr80211_create(gr80211_ctx **out, int device);
 void gr80211_destroy(gr80211_ctx *ctx);
@@ -178,6 +196,22 @@ int gr80211_decode_batch(gr80211_ctx *ctx, const float *d_llr, uint64_t llr_floa
                          const gr80211_dec_desc *desc, int n_frames, unsigned flags,
                          uint8_t *d_out, int out_stride, int32_t *d_out_len, int32_t *d_n_pdu,
                          uint8_t *d_bits, int bits_stride, void *stream);
+
+/*
+ * Synthetic transmitter: PSDU bytes -> 20-MHz baseband frames, the waveform of the reference's Python generator
+ * (tools/phy80211.py genFromMpdu 80-117, genFromAmpdu 119-181, genFinalSig 1077-1094; the C++ blocks
+ * encode / modulation / pad of lib/ implement the same standard clauses for the GNU Radio flowgraph).
+ * Frame i is written to d_iq0[desc[i].out_off ...] (first chain) and, for two-stream frames, d_iq1 (second
+ * chain; may be NULL when no frame has two streams); samples outside the frames are left untouched, so the
+ * caller zeroes the arena and chooses the gaps.  d_n_samples (nullable) receives the sample count of each
+ * frame, or -1 for a descriptor that was rejected (unsupported modulation or length, PSDU outside d_psdu, frame
+ * outside the arena) -- such frames write nothing.  gr80211_tx_samples is the same count on the host (-1 if
+ * the combination is not supported).
+ */
+int gr80211_tx_samples(int format, int mcs, int nss, int psdu_len);
+int gr80211_tx_batch(gr80211_ctx *ctx, const uint8_t *d_psdu, uint64_t psdu_bytes, const gr80211_tx_desc *desc,
+                     int n_frames, unsigned flags, void *d_iq0, void *d_iq1, uint64_t arena_len,
+                     int32_t *d_n_samples, void *stream);
 
 /* Device memory helpers so that a C / FFI caller needs no HIP binding of its own. */
 void *gr80211_dev_alloc(gr80211_ctx *ctx, size_t bytes);

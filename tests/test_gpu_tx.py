@@ -1,0 +1,169 @@
+"""The GPU transmitter (gr80211_tx_batch) against the waveforms of the reference's Python generator (golden
+fixtures), against the numpy generator of this package (pinned to the same fixtures by test_txgen.py) on cases the
+fixtures do not hold, and closed loop through the GPU receiver.  Bits are exact by construction of the comparison
+(a single wrong coded bit moves a constellation point by >= 0.15); samples are float32 IDFT outputs, compared to
+2e-6 of the frame's peak."""
+import numpy as np
+import pytest
+
+from util import H22, awgn, golden_frames
+
+pytestmark = pytest.mark.gpu
+
+TOL = 2e-6
+
+
+def run_tx(pkg, rxctx, jobs, gap=64):
+    """jobs: list of dict(fmt, mcs, nss, psdu (bytes), scale, cfo_rad, scrambler).  Returns list of [nss][N] arrays."""
+    import torch
+    d = rxctx.make_tx_desc(len(jobs))
+    blob, pos = b"", gap
+    for i, j in enumerate(jobs):
+        ns = rxctx.tx_samples(j["fmt"], j["mcs"], j.get("nss", 1), len(j["psdu"]))
+        assert ns > 0, j
+        d[i]["out_off"], d[i]["psdu_off"], d[i]["psdu_len"] = pos, len(blob), len(j["psdu"])
+        d[i]["format"], d[i]["mcs"], d[i]["nss"] = j["fmt"], j["mcs"], j.get("nss", 1)
+        d[i]["scale"], d[i]["cfo_rad"], d[i]["scrambler"] = j.get("scale", 1.0), j.get("cfo_rad", 0.0), j.get("scrambler", 93)
+        blob += j["psdu"]
+        pos += ns + gap
+    psdu = torch.from_numpy(np.frombuffer(blob, np.uint8).copy()).cuda()
+    iq0 = torch.zeros(pos, dtype=torch.complex64, device="cuda")
+    iq1 = torch.zeros(pos, dtype=torch.complex64, device="cuda")
+    ns = rxctx.tx_batch(psdu, d, len(jobs), iq0, iq1).cpu().numpy()
+    a0, a1 = iq0.cpu().numpy(), iq1.cpu().numpy()
+    out, covered = [], np.zeros(pos, bool)
+    for i, j in enumerate(jobs):
+        o = int(d[i]["out_off"])
+        assert ns[i] == rxctx.tx_samples(j["fmt"], j["mcs"], j.get("nss", 1), len(j["psdu"]))
+        covered[o:o + ns[i]] = True
+        out.append(np.stack([a0[o:o + ns[i]], a1[o:o + ns[i]]]))
+    assert not a0[~covered].any() and not a1[~covered].any()   # nothing written outside the frames
+    return out
+
+
+def psdu_of(tx, f):
+    return tx.ampdu_vht([f["mpdu"]]) if f["fmt"] == 2 else f["mpdu"]
+
+
+def test_tx_equals_python_reference_waveforms(pkg, rxctx):
+    tx = pkg.txgen
+    gf = golden_frames()
+    jobs = [dict(fmt=f["fmt"], mcs=f["mcs"], nss=f["nss"], psdu=psdu_of(tx, f), scale=12.0 * np.sqrt(f["nss"]),
+                 cfo_rad=-f["rad"]) for f in gf]
+    got = run_tx(pkg, rxctx, jobs)
+    for f, g in zip(gf, got):
+        sig = g.astype(np.complex128)
+        sig = (H22 @ sig) if f["nss"] == 2 else sig[:1]
+        ref = f["iq"][:, 400:400 + sig.shape[1]]
+        assert sig.shape[1] == f["iq"].shape[1] - 800, f["name"]
+        err = np.abs(sig - ref).max()
+        assert err < TOL * 12.0 * 4, (f["name"], err)
+
+
+CASES = [(0, m, 1, 40 + 37 * m) for m in range(8)] + [(1, m, 1, 50 + 41 * m) for m in range(16)] + \
+        [(2, m, 1, 30 + 29 * m) for m in range(9)] + [(2, m, 2, 45 + 31 * m) for m in range(9)] + \
+        [(0, 0, 1, 1), (0, 7, 1, 4095), (2, 8, 1, 4095), (2, 0, 1, 1), (1, 15, 2, 4095), (2, 8, 2, 3), (1, 0, 1, 2304)]
+
+
+def test_tx_equals_numpy_generator_every_mcs(pkg, rxctx):
+    tx = pkg.txgen
+    rng = np.random.default_rng(77)
+    jobs, want = [], []
+    for k, (fmt, mcs, nss, nbytes) in enumerate(CASES):
+        payload = rng.integers(0, 256, nbytes, dtype=np.uint8).tobytes()
+        seed = int(rng.integers(1, 128))
+        if fmt == 2:
+            # gen_frame wraps the MPDU into a one-subframe A-MPDU itself; the GPU gets that A-MPDU
+            mp = tx.make_mpdu(min(max(nbytes, 8), 4088), rng)
+            payload = tx.ampdu_vht([mp])
+            sig, m = tx.gen_frame(fmt, mcs, nss, mp, scrambler=seed)
+        else:
+            sig, m = tx.gen_frame(fmt, mcs, nss, payload, scrambler=seed)
+        jobs.append(dict(fmt=fmt, mcs=mcs, nss=nss, psdu=payload, scrambler=seed, scale=1.0 + 0.25 * (k % 3)))
+        want.append(sig * jobs[-1]["scale"])
+    got = run_tx(pkg, rxctx, jobs)
+    for j, g, w in zip(jobs, got, want):
+        assert g.shape[1] == w.shape[1], j
+        err = np.abs(g[: w.shape[0]].astype(np.complex128) - w).max()
+        assert err < TOL * 4, (j["fmt"], j["mcs"], j["nss"], len(j["psdu"]), err)
+        if w.shape[0] == 1:
+            assert not g[1].any()
+
+
+def test_tx_cfo_and_multi_subframe(pkg, rxctx):
+    tx = pkg.txgen
+    rng = np.random.default_rng(78)
+    ms = [tx.make_mpdu(96, rng) for _ in range(3)]
+    sig, m = tx.gen_frame(2, 6, 1, None, n_mpdu_list=ms)
+    rad = 2 * np.pi * 180e3 / 20e6
+    want = sig[0] * 3.0 * np.exp(1j * rad * np.arange(sig.shape[1]))
+    got = run_tx(pkg, rxctx, [dict(fmt=2, mcs=6, nss=1, psdu=tx.ampdu_vht(ms), scale=3.0, cfo_rad=np.float32(rad))])
+    want32 = sig[0] * 3.0 * np.exp(1j * float(np.float32(rad)) * np.arange(sig.shape[1]))
+    assert np.abs(got[0][0] - want32).max() < TOL * 12
+    assert np.abs(got[0][0] - want).max() < 1e-3
+
+
+def test_tx_rejects_bad_descriptors(pkg, rxctx):
+    import torch
+    d = rxctx.make_tx_desc(6)
+    psdu = torch.zeros(5000, dtype=torch.uint8, device="cuda")
+    iq = torch.zeros(20000, dtype=torch.complex64, device="cuda")
+    for i, (fmt, mcs, nss, ln, off, out) in enumerate([(0, 8, 1, 100, 0, 0), (2, 9, 1, 100, 0, 0), (2, 3, 3, 100, 0, 0),
+                                                       (0, 0, 1, 4096, 0, 0), (0, 3, 1, 100, 4950, 0),
+                                                       (0, 3, 1, 100, 0, 19900)]):
+        d[i]["format"], d[i]["mcs"], d[i]["nss"], d[i]["psdu_len"], d[i]["psdu_off"], d[i]["out_off"] = fmt, mcs, nss, ln, off, out
+    ns = rxctx.tx_batch(psdu, d, 6, iq, None).cpu().numpy()
+    assert (ns == -1).all() and not iq.cpu().numpy().any()
+    assert rxctx.tx_samples(2, 9, 1, 100) == -1 and rxctx.tx_samples(0, 0, 1, 100) == 400 + 80 * 35
+    # a two-stream frame without a second arena is rejected too
+    d2 = rxctx.make_tx_desc(1)
+    d2[0]["format"], d2[0]["mcs"], d2[0]["psdu_len"] = 1, 9, 50
+    assert int(rxctx.tx_batch(psdu, d2, 1, iq, None).cpu()[0]) == -1
+
+
+def test_closed_loop_unique_frames(pkg, rxctx):
+    """Transmit 6000 frames with unique payloads on the GPU (all formats, both stream counts), add noise, receive
+    them on the GPU: every MPDU must come back bit for bit."""
+    import torch
+    tx = pkg.txgen
+    rng = np.random.default_rng(79)
+    n = 6000
+    kinds = [(0, 4, 1), (0, 7, 1), (1, 3, 1), (1, 7, 1), (2, 4, 1), (2, 8, 1), (1, 11, 2), (2, 7, 2)]
+    d = rxctx.make_tx_desc(n)
+    blob, mpdus, pos, sync = bytearray(), [], 100, []
+    for i in range(n):
+        fmt, mcs, nss = kinds[i % len(kinds)]
+        nb = int(rng.integers(40, 700))
+        mp = tx.make_mpdu(nb, rng)
+        ps = tx.ampdu_vht([mp]) if fmt == 2 else mp
+        ns = rxctx.tx_samples(fmt, mcs, nss, len(ps))
+        d[i]["out_off"], d[i]["psdu_off"], d[i]["psdu_len"] = pos, len(blob), len(ps)
+        d[i]["format"], d[i]["mcs"], d[i]["nss"], d[i]["scale"] = fmt, mcs, nss, 12.0 * np.sqrt(nss)
+        blob += ps
+        mpdus.append(mp)
+        sync.append(pos + 176)
+        pos += ns + 120
+    psdu = torch.from_numpy(np.frombuffer(bytes(blob), np.uint8).copy()).cuda()
+    t0 = torch.zeros(pos, dtype=torch.complex64, device="cuda")
+    t1 = torch.zeros(pos, dtype=torch.complex64, device="cuda")
+    ns = rxctx.tx_batch(psdu, d, n, t0, t1)
+    assert int((ns > 0).sum()) == n
+    h = torch.tensor(H22, dtype=torch.complex64, device="cuda")
+    two = torch.zeros(pos, dtype=torch.bool, device="cuda")
+    nsc = ns.cpu().numpy()
+    for i in range(n):
+        if kinds[i % len(kinds)][2] == 2:
+            two[int(d[i]["out_off"]): int(d[i]["out_off"]) + int(nsc[i])] = True
+    r0 = torch.where(two, h[0, 0] * t0 + h[0, 1] * t1, t0)
+    r1 = torch.where(two, h[1, 0] * t0 + h[1, 1] * t1, torch.zeros_like(t0))
+    g = torch.Generator(device="cuda").manual_seed(5)
+    sigma = 12.0 / np.sqrt(64.0) * 10 ** (-36.0 / 20) / np.sqrt(2.0)
+    r0 = (r0 + sigma * torch.view_as_complex(torch.randn((pos, 2), generator=g, device="cuda"))).contiguous()
+    r1 = (r1 + sigma * torch.view_as_complex(torch.randn((pos, 2), generator=g, device="cuda"))).contiguous()
+    sync = np.array(sync, np.uint64)
+    navail = (nsc - 176 + 100).astype(np.uint32)
+    res = rxctx.rx_batch(r0, r1, rxctx.make_desc(sync, navail), n, out_stride=768)
+    rxctx.sync()
+    out, out_len, n_pdu = res["out"].cpu().numpy(), res["out_len"].cpu().numpy(), res["n_pdu"].cpu().numpy()
+    bad = [i for i in range(n) if n_pdu[i] != 1 or bytes(out[i, 3:out_len[i] - 1]) != mpdus[i]]
+    assert not bad, (len(bad), bad[:10])
