@@ -157,7 +157,7 @@ def test_closed_loop_unique_frames(pkg, rxctx):
     r0 = torch.where(two, h[0, 0] * t0 + h[0, 1] * t1, t0)
     r1 = torch.where(two, h[1, 0] * t0 + h[1, 1] * t1, torch.zeros_like(t0))
     g = torch.Generator(device="cuda").manual_seed(5)
-    sigma = 12.0 / np.sqrt(64.0) * 10 ** (-36.0 / 20) / np.sqrt(2.0)
+    sigma = 12.0 / 64.0 * 10 ** (-36.0 / 20) / np.sqrt(2.0)
     r0 = (r0 + sigma * torch.view_as_complex(torch.randn((pos, 2), generator=g, device="cuda"))).contiguous()
     r1 = (r1 + sigma * torch.view_as_complex(torch.randn((pos, 2), generator=g, device="cuda"))).contiguous()
     sync = np.array(sync, np.uint64)
