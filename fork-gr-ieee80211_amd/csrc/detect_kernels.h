@@ -22,7 +22,8 @@ void launch_det_trigger_sync(const void *iq, long long n, const long long *rise,
                              long long *seen_at, long long *scan_lo, long long *prev_seen, long long *pos, float *rad,
                              float *snr, float *rssi, uint32_t *emitted, uint32_t *blk, uint32_t *totals, hipStream_t s);
 void launch_det_emit(const uint32_t *emitted, long long nruns, const uint32_t *blk, const long long *pos, const float *rad,
-                     const float *snr, const float *rssi, long long n, gr80211_frame_desc *desc, int max_desc, hipStream_t s);
+                     const float *snr, const float *rssi, long long n, gr80211_frame_desc *desc, int max_desc, uint32_t mu_pos,
+                     hipStream_t s);
 
 // `signal`'s trigger search over nd sync bytes whose L-SIG results are in info: out[0 .. *count) = the bytes it deals
 // with, in order, n_avail cut to the frame's own samples.  jump_a, jump_b, path: nd + 1 entries each.

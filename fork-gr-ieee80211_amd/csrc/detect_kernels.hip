@@ -539,7 +539,8 @@ __global__ void k_det_flag_count(const uint32_t *__restrict__ emitted, long long
 
 __global__ void k_det_emit(const uint32_t *__restrict__ emitted, long long nruns, const uint32_t *__restrict__ blk,
                            const long long *__restrict__ pos, const float *__restrict__ rad, const float *__restrict__ snr,
-                           const float *__restrict__ rssi, long long n, gr80211_frame_desc *__restrict__ desc, int max_desc)
+                           const float *__restrict__ rssi, long long n, gr80211_frame_desc *__restrict__ desc, int max_desc,
+                           uint32_t mu_pos)
 {
     __shared__ uint32_t s[256];
     const long long r = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -562,7 +563,8 @@ __global__ void k_det_emit(const uint32_t *__restrict__ emitted, long long nruns
     d.rad = rad[r];
     d.snr = snr[r];
     d.rssi = rssi[r];
-    d.reserved[0] = d.reserved[1] = 0;
+    d.mu_pos = mu_pos;
+    d.reserved = 0;
     desc[o] = d;
 }
 
@@ -679,11 +681,12 @@ void launch_det_trigger_sync(const void *iq, long long n, const long long *rise,
 }
 
 void launch_det_emit(const uint32_t *emitted, long long nruns, const uint32_t *blk, const long long *pos, const float *rad,
-                     const float *snr, const float *rssi, long long n, gr80211_frame_desc *desc, int max_desc, hipStream_t s)
+                     const float *snr, const float *rssi, long long n, gr80211_frame_desc *desc, int max_desc, uint32_t mu_pos,
+                     hipStream_t s)
 {
     if (nruns <= 0) return;
     const int nb = (int)((nruns + 255) / 256);
-    hipLaunchKernelGGL(k_det_emit, dim3(nb), dim3(256), 0, s, emitted, nruns, blk, pos, rad, snr, rssi, n, desc, max_desc);
+    hipLaunchKernelGGL(k_det_emit, dim3(nb), dim3(256), 0, s, emitted, nruns, blk, pos, rad, snr, rssi, n, desc, max_desc, mu_pos);
 }
 
 // path (capacity nd + 1 entries) and two jump buffers of nd + 1 entries; *count = bytes on the path.

@@ -31,6 +31,7 @@ struct gr80211_ctx {
     Buf tx_desc;
     uint32_t *det_totals_h = nullptr;  // pinned
     SchedTotals *totals_h = nullptr;  // pinned
+    uint32_t mu_pos = 0;  // MU group position written into the descriptors frame detection makes
     bool profiling = false;
     bool split_decode = false;  // GR80211_SPLIT_DECODE=1: forward pass and traceback as two kernels
     hipEvent_t ev[7] = {};
@@ -256,7 +257,7 @@ void detect_emit(gr80211_ctx *c, hipStream_t s, long long nruns, long long n, gr
     long long *rise = (long long *)c->det_runs.p, *pos = rise + 5 * nruns;
     float *rad = (float *)c->det_rec.p, *snr = rad + nruns, *rssi = snr + nruns;
     uint32_t *emitted = (uint32_t *)(rssi + nruns), *blk2 = emitted + nruns;
-    launch_det_emit(emitted, nruns, blk2, pos, rad, snr, rssi, n, d_desc, max_desc, s);
+    launch_det_emit(emitted, nruns, blk2, pos, rad, snr, rssi, n, d_desc, max_desc, c->mu_pos, s);
 }
 
 }  // namespace
@@ -551,6 +552,13 @@ int gr80211_copy_d2h(gr80211_ctx *c, void *h_dst, const void *d_src, size_t byte
     hipStream_t s = pick(c, stream);
     HIP_TRY(c, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
+    return GR80211_OK;
+}
+
+int gr80211_set_mu_pos(gr80211_ctx *c, int mu_pos)
+{
+    if (!c || mu_pos < 0 || mu_pos > 1) return GR80211_ERR_ARG;
+    c->mu_pos = (uint32_t)mu_pos;
     return GR80211_OK;
 }
 

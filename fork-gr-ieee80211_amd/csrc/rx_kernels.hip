@@ -227,19 +227,10 @@ __device__ void parse_ht(const uint8_t *b, ModS *m)
     m->nLTF = ltf_count(m->nSS);
     m->nSym = (len * 8 + 22) / m->nDBPS + (((len * 8 + 22) % m->nDBPS) != 0);
 }
-// lib/cloud80211phy.cc:1090-1178 with modParserVht (1225-1323); false = outside this build's
-// scope (MU group id, MCS 10..15 for which the reference keeps stale state).
-__device__ bool parse_vhta(const uint8_t *b, ModS *m)
+// Rate-dependent fields of a VHT MCS (modParserVht, lib/cloud80211phy.cc:1225-1323); false for MCS 10..15, for
+// which the reference keeps the fields of an earlier packet.
+__device__ bool set_vht_mcs(int mcs, ModS *m)
 {
-    int gid = 0, nsts = 0, mcs = 0;
-    for (int i = 0; i < 6; i++) gid |= b[i + 4] << i;
-    m->format = GR80211_F_VHT;
-    m->nSymSamp = b[24] ? 72 : 80;
-    m->ampdu = 1;
-    if (!(gid == 0 || gid == 63)) return false;
-    for (int i = 0; i < 3; i++) nsts |= b[i + 10] << i;
-    for (int i = 0; i < 4; i++) mcs |= b[i + 28] << i;
-    m->nSS = nsts + 1;
     m->mcs = mcs;
     if (mcs > 9) return false;
     set_rate_ladder(mcs, m);
@@ -248,6 +239,38 @@ __device__ bool parse_vhta(const uint8_t *b, ModS *m)
     m->nCBPS = m->nCBPSS * m->nSS;
     set_ndbps(m);
     m->nLTF = ltf_count(m->nSS);
+    return true;
+}
+// lib/cloud80211phy.cc:1090-1178.  Returns 1 for a single-user frame, 2 for an MU frame (group id 1..62: one
+// stream for this station, two VHT-LTFs, modulation known after VHT-SIG-B), 0 for an invalid MCS.
+__device__ int parse_vhta(const uint8_t *b, ModS *m)
+{
+    int gid = 0, nsts = 0, mcs = 0;
+    for (int i = 0; i < 6; i++) gid |= b[i + 4] << i;
+    m->format = GR80211_F_VHT;
+    m->nSymSamp = b[24] ? 72 : 80;
+    m->ampdu = 1;
+    if (!(gid == 0 || gid == 63)) {
+        m->nLTF = 2;
+        m->nSS = 1;
+        m->nSD = 52;
+        return 2;
+    }
+    for (int i = 0; i < 3; i++) nsts |= b[i + 10] << i;
+    for (int i = 0; i < 4; i++) mcs |= b[i + 28] << i;
+    m->nSS = nsts + 1;
+    return set_vht_mcs(mcs, m) ? 1 : 0;
+}
+// lib/cloud80211phy.cc:1184-1192: VHT-SIG-B of an MU frame, 16 bits of length and 4 bits of MCS.
+__device__ bool parse_vhtb_mu(const uint8_t *b, ModS *m)
+{
+    int l = 0, mcs = 0;
+    for (int i = 0; i < 16; i++) l |= b[i] << i;
+    for (int i = 0; i < 4; i++) mcs |= b[i + 16] << i;
+    if (!set_vht_mcs(mcs, m)) return false;
+    m->len = l * 4;
+    m->nSym = (m->len * 8 + 16 + 6) / m->nDBPS + (((m->len * 8 + 16 + 6) % m->nDBPS) != 0);
+    m->nLTF = 2;
     return true;
 }
 // lib/cloud80211phy.cc:1180-1223, single-user branch
@@ -294,7 +317,7 @@ __global__ __launch_bounds__(64) void k_preamble(const c32 *__restrict__ iq0, co
     __shared__ unsigned long long s_mask[48];
     __shared__ uint8_t s_bits[48];
     __shared__ ModS s_m;
-    __shared__ int s_ctl[8];  // 0 status, 1 lsig_mcs, 2 lsig_len, 3 nsamp, 4 fmt, 5 trellis, 6 data_off
+    __shared__ int s_ctl[8];  // 0 status, 1 lsig_mcs, 2 lsig_len, 3 nsamp, 4 fmt, 5 trellis, 6 data_off, 7 MU frame
     __shared__ float s_snr[2];
     __shared__ double s_red[64];
 
@@ -395,7 +418,10 @@ __global__ __launch_bounds__(64) void k_preamble(const c32 *__restrict__ iq0, co
         if (lane == 0) {
             if (check_vhta(s_bits)) {
                 s_ctl[4] = GR80211_F_VHT;
-                if (!parse_vhta(s_bits, &s_m)) s_ctl[0] = GR80211_ST_DROP_UNSUPPORTED;
+                const int kind = parse_vhta(s_bits, &s_m);
+                s_ctl[7] = kind == 2;
+                // MU frames are the one-antenna block's business (lib/demod_impl.cc:347-379); demod2 has no such branch
+                if (kind == 0 || (kind == 2 && two_ant)) s_ctl[0] = GR80211_ST_DROP_UNSUPPORTED;
             } else {
                 s_ctl[4] = -1;
             }
@@ -446,7 +472,18 @@ __global__ __launch_bounds__(64) void k_preamble(const c32 *__restrict__ iq0, co
         c32 h[4], hi[4];
         c32 hn = mk(0.0f, 0.0f);
         c32 pl1 = mk(0.0f, 0.0f), pl2 = mk(0.0f, 0.0f);  // LTF-derived pilot references (pilot lanes)
-        if (nss == 1) {
+        const bool mu = s_ctl[7] != 0;
+        if (mu) {
+            // this station's stream out of the two VHT-LTFs of a two-user MU frame (lib/demod_impl.cc:347-379);
+            // the second LTF's sequence has its pilot tones negated (LTF_NL_28_F_FLOAT_VHT22)
+            const c32 F1 = wave_fft64(load_samp(in0, off + SHIFT + lane, nvalid, rad), lane);
+            const c32 F2 = wave_fft64(load_samp(in0, off + 80 + SHIFT + lane, nvalid, rad), lane);
+            if (nused) {
+                if (d.mu_pos == 0) hn = cdivf(csub(F1, F2), ltfn * 2.0f);
+                else hn = cdivf(cadd(cdivf(F1, ltfn), cdivf(F2, is_pilot_bin(bin) ? -ltfn : ltfn)), 2.0f);
+            }
+            chan1[(size_t)f * 64 + bin] = hn;
+        } else if (nss == 1) {
             // lib/demod_impl.cc:380-392
             const c32 F1 = wave_fft64(load_samp(in0, off + SHIFT + lane, nvalid, rad), lane);
             if (nused) hn = cdivf(F1, ltfn);
@@ -576,9 +613,13 @@ __global__ __launch_bounds__(64) void k_preamble(const c32 *__restrict__ iq0, co
                 __syncthreads();
             }
             if (lane == 0) {
-                parse_vhtb(s_bits, &s_m);
+                bool known = true;
+                if (mu) known = parse_vhtb_mu(s_bits, &s_m);
+                else parse_vhtb(s_bits, &s_m);
                 const ModS m = s_m;
-                if (m.len == 0 && m.nSym == 0) {
+                if (!known) {
+                    s_ctl[0] = GR80211_ST_DROP_UNSUPPORTED;
+                } else if (m.len == 0 && m.nSym == 0) {
                     // NDP: one antenna reports the raw VHT-LTF samples (lib/demod_impl.cc:238-249,265-271);
                     // the two-antenna block requires len > 0 and drops it (lib/demod2_impl.cc:159)
                     s_ctl[0] = two_ant ? GR80211_ST_DROP_LEN_CHECK : GR80211_ST_NDP;

@@ -21,7 +21,7 @@ FLAG_DESC_ON_DEVICE = 1
 
 class FrameDesc(C.Structure):
     _fields_ = [("sync_off", C.c_uint64), ("n_avail", C.c_uint32), ("rad", C.c_float),
-                ("snr", C.c_float), ("rssi", C.c_float), ("reserved", C.c_uint32 * 2)]
+                ("snr", C.c_float), ("rssi", C.c_float), ("mu_pos", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class FrameInfo(C.Structure):
@@ -40,7 +40,7 @@ class DecDesc(C.Structure):
 
 
 FRAME_DESC_DTYPE = np.dtype([("sync_off", "<u8"), ("n_avail", "<u4"), ("rad", "<f4"), ("snr", "<f4"),
-                             ("rssi", "<f4"), ("reserved", "<u4", (2,))])
+                             ("rssi", "<f4"), ("mu_pos", "<u4"), ("reserved", "<u4")])
 FRAME_INFO_DTYPE = np.dtype(
     [(n, "<i4") for n in ("status", "lsig_mcs", "lsig_len", "nsamp", "format", "mcs", "len", "cr", "ampdu",
                           "trellis", "total", "nSym", "nSS", "nLTF", "nCBPS", "nDBPS", "nBPSCS", "mod")] +
@@ -61,7 +61,7 @@ EXPORTS = [
     "gr80211_create", "gr80211_destroy", "gr80211_last_error", "gr80211_sync", "gr80211_rx_batch", "gr80211_signal_batch", "gr80211_detect", "gr80211_rx_capture",
     "gr80211_demod_batch", "gr80211_decode_batch", "gr80211_dev_alloc", "gr80211_dev_free",
     "gr80211_copy_h2d", "gr80211_copy_d2h", "gr80211_set_profiling", "gr80211_last_timing",
-    "gr80211_version", "gr80211_table_checksum", "gr80211_tx_samples", "gr80211_tx_batch",
+    "gr80211_version", "gr80211_table_checksum", "gr80211_tx_samples", "gr80211_tx_batch", "gr80211_set_mu_pos",
 ]
 
 _lib = None
@@ -97,6 +97,7 @@ def load_library():
     L.gr80211_copy_h2d.argtypes = [vp, vp, vp, C.c_size_t, vp]
     L.gr80211_copy_d2h.argtypes = [vp, vp, vp, C.c_size_t, vp]
     L.gr80211_set_profiling.argtypes = [vp, C.c_int]
+    L.gr80211_set_mu_pos.argtypes = [vp, C.c_int]
     L.gr80211_last_timing.argtypes = [vp, C.POINTER(C.c_float), C.c_int]
     L.gr80211_tx_samples.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
     L.gr80211_tx_batch.argtypes = [vp, vp, C.c_uint64, vp, C.c_int, C.c_uint, vp, vp, C.c_uint64, vp, vp]
@@ -169,6 +170,9 @@ class RxContext:
     def set_profiling(self, on):
         self._check(self.lib.gr80211_set_profiling(self.h, 1 if on else 0), "set_profiling")
 
+    def set_mu_pos(self, pos):
+        self._check(self.lib.gr80211_set_mu_pos(self.h, int(pos)), "set_mu_pos")
+
     def last_timing(self):
         ms = (C.c_float * 6)()
         self._check(self.lib.gr80211_last_timing(self.h, ms, 6), "last_timing")
@@ -178,7 +182,7 @@ class RxContext:
         self._check(self.lib.gr80211_sync(self.h, self._stream()), "sync")
 
     @staticmethod
-    def make_desc(sync_off, n_avail, rad=None, snr=None, rssi=None):
+    def make_desc(sync_off, n_avail, rad=None, snr=None, rssi=None, mu_pos=None):
         n = len(sync_off)
         d = np.zeros(n, dtype=FRAME_DESC_DTYPE)
         d["sync_off"] = sync_off
@@ -189,6 +193,8 @@ class RxContext:
             d["snr"] = snr
         if rssi is not None:
             d["rssi"] = rssi
+        if mu_pos is not None:
+            d["mu_pos"] = mu_pos
         return d
 
     def _desc_arg(self, desc):

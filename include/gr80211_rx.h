@@ -63,7 +63,9 @@ typedef struct {
     float rad;  /* CFO in rad/sample */
     float snr;
     float rssi;
-    uint32_t reserved[2];
+    uint32_t mu_pos;   /* this station's position (0 or 1) in a VHT MU group: the mupos argument of
+                          ieee80211::demod::make(mupos, mugid) (lib/demod_impl.cc:28-39); only read for MU frames */
+    uint32_t reserved;
 } gr80211_frame_desc; /* 32 bytes */
 
 /*
@@ -162,6 +164,13 @@ int gr80211_detect(gr80211_ctx *ctx, const void *d_iq, uint64_t n_samples, gr802
 int gr80211_rx_capture(gr80211_ctx *ctx, const void *d_iq0, const void *d_iq1, uint64_t n_samples, uint8_t *d_out,
                        int out_stride, int32_t *d_out_len, int32_t *d_n_pdu, int max_frames,
                        gr80211_frame_desc *d_desc_out, int *n_frames, void *stream);
+
+/*
+ * Position of this station in VHT MU groups (0 or 1; ieee80211::demod::make(mupos, mugid), lib/demod_impl.cc:28-39)
+ * for the descriptors gr80211_detect / gr80211_rx_capture make themselves; callers that build descriptors set
+ * gr80211_frame_desc.mu_pos.  Default 0.
+ */
+int gr80211_set_mu_pos(gr80211_ctx *ctx, int mu_pos);
 
 /*
  * signal/signal2 (and the format detection of demod/demod2) only: L-SIG decode, format detection,

@@ -33,6 +33,8 @@ class Frame(C.Structure):
         ("sig_bits", C.c_uint8 * 48),
         ("sigb_bits", C.c_uint8 * 26),
         ("mu2x1chan", C.c_float * 256),
+        ("sumu", C.c_int),
+        ("mu_pos", C.c_int),
     ]
 
 
@@ -62,6 +64,8 @@ def lib():
                                  u8, C.c_int, ip, u8]
         L.orc_rx_frame.argtypes = [fp, fp, C.c_int, C.c_float, C.POINTER(Frame), fp, C.c_int,
                                    u8, C.c_int, ip, ip]
+        L.orc_rx_frame_mu.argtypes = [fp, fp, C.c_int, C.c_float, C.c_int, C.POINTER(Frame), fp, C.c_int,
+                                      u8, C.c_int, ip, ip]
         L.orc_sig_viterbi.argtypes = [fp, u8, C.c_int]
         L.orc_viterbi_bits.argtypes = [fp, C.c_int, C.c_int, C.c_int, u8]
         L.orc_get_table.argtypes = [C.c_char_p, ip, C.c_int, ip]
@@ -139,7 +143,7 @@ def decode(llr, format, length, cr, mcs, ampdu, trellis, want_bits=False):
     return res
 
 
-def rx_frame(iq0, iq1, sync_idx, rad=0.0, want_llr=True):
+def rx_frame(iq0, iq1, sync_idx, rad=0.0, want_llr=True, mu_pos=0):
     """Run signal -> demod/demod2 -> decode on one frame.
 
     iq0/iq1: complex64 capture(s) of each antenna (iq1 None for the SISO demod block);
@@ -159,8 +163,8 @@ def rx_frame(iq0, iq1, sync_idx, rad=0.0, want_llr=True):
     out = np.zeros(8192, dtype=np.uint8)
     olen = C.c_int(0)
     npdu = C.c_int(0)
-    st = lib().orc_rx_frame(p0, p1, navail, np.float32(rad), C.byref(f), _fp(llr), cap,
-                            _u8(out), len(out), C.byref(olen), C.byref(npdu))
+    st = lib().orc_rx_frame_mu(p0, p1, navail, np.float32(rad), int(mu_pos), C.byref(f), _fp(llr), cap,
+                               _u8(out), len(out), C.byref(olen), C.byref(npdu))
     blob = bytes(out[: olen.value])
     res = dict(status=st, frame=f, n_pdu=npdu.value, blob=blob, pdus=split_pdus(blob))
     if want_llr and st == 0:

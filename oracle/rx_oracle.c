@@ -399,8 +399,9 @@ static int parse_vht_mod(int mcs, orc_mod_t *m)
     return 1;
 }
 
-/* lib/cloud80211phy.cc:1090-1178.  Returns 0 when the frame is outside this build's scope
- * (MU group id, invalid MCS). */
+/* lib/cloud80211phy.cc:1090-1178.  Returns 1 for a single-user frame, 2 for an MU frame (group id 1..62: the
+ * modulation is only known after VHT-SIG-B), 0 when the MCS is invalid (the reference then keeps fields of an
+ * earlier packet). */
 static int parse_vhta(const uint8_t *b, orc_mod_t *m)
 {
     int gid = 0, nsts = 0, mcs = 0;
@@ -408,11 +409,29 @@ static int parse_vhta(const uint8_t *b, orc_mod_t *m)
     m->format = ORC_F_VHT;
     m->nSymSamp = b[24] ? 72 : 80;
     m->ampdu = 1;
-    if (!(gid == 0 || gid == 63)) return 0;
+    if (!(gid == 0 || gid == 63)) {
+        m->nLTF = 2;
+        m->nSS = 1;
+        m->nSD = 52;
+        return 2;
+    }
     for (int i = 0; i < 3; i++) nsts |= b[i + 10] << i;
     for (int i = 0; i < 4; i++) mcs |= b[i + 28] << i;
     m->nSS = nsts + 1;
     return parse_vht_mod(mcs, m);
+}
+
+/* lib/cloud80211phy.cc:1184-1192, MU branch of VHT-SIG-B: 16 bits of length, 4 bits of MCS. */
+static int parse_vhtb_mu(const uint8_t *b, orc_mod_t *m)
+{
+    int l = 0, mcs = 0;
+    for (int i = 0; i < 16; i++) l |= b[i] << i;
+    for (int i = 0; i < 4; i++) mcs |= b[i + 16] << i;
+    if (!parse_vht_mod(mcs, m)) return 0;
+    m->len = l * 4;
+    m->nSym = (m->len * 8 + 16 + 6) / m->nDBPS + (((m->len * 8 + 16 + 6) % m->nDBPS) != 0);
+    m->nLTF = 2;
+    return 1;
 }
 
 /* lib/cloud80211phy.cc:1180-1223, SU branch. */
@@ -676,6 +695,24 @@ static void nl2_update(const src_t *s, int off, chan_t *c, int vht, cf *q0, cf *
         }
 }
 
+/* lib/demod_impl.cc:347-379: this station's stream out of the two VHT-LTFs of a two-user MU frame.  The second
+ * LTF's sequence is LTF_NL_28_F_FLOAT_VHT22 = the HT/VHT-LTF with its pilot tones negated. */
+static void mu_chan_est(const src_t *s, int off, int mu_pos, chan_t *c)
+{
+    cf F1[64], F2[64];
+    fft_at(s, 0, off, F1);
+    fft_at(s, 0, off + 80, F2);
+    for (int i = 0; i < 64; i++)
+        if (nl_used(i)) {
+            if (mu_pos == 0) {
+                c->h[i][0] = (F1[i] - F2[i]) / (T_LTF_NL[i] * 2.0f);
+            } else {
+                float l22 = is_pilot_bin(i) ? -T_LTF_NL[i] : T_LTF_NL[i];
+                c->h[i][0] = (F1[i] / T_LTF_NL[i] + F2[i] / l22) / 2.0f;
+            }
+        }
+}
+
 /* lib/demod_impl.cc:380-392 (one LTF), lib/demod2_impl.cc:372-463 (two streams) */
 static void nl_chan_est(const src_t *s, int off, const orc_mod_t *m, int two_ant, chan_t *c)
 {
@@ -815,7 +852,9 @@ int orc_demod(const float *in0_ri, const float *in1_ri, int navail, float rad, o
         orc_sig_viterbi(llrvht, f->sig_bits, 48);
         if (check_vhta(f->sig_bits)) {
             fmt = ORC_F_VHT;
-            if (!parse_vhta(f->sig_bits, m)) { f->status = ORC_DROP_UNSUPPORTED; goto done; }
+            int rc = parse_vhta(f->sig_bits, m);
+            if (!rc) { f->status = ORC_DROP_UNSUPPORTED; goto done; }
+            f->sumu = rc == 2;
             pos = 160;
         } else {
             orc_sig_viterbi(llrht, f->sig_bits, 48);
@@ -834,9 +873,19 @@ int orc_demod(const float *in0_ri, const float *in1_ri, int navail, float rad, o
         /* two streams on one antenna: followed up to VHT-SIG-B to see whether it is a sounding NDP
          * (demod_impl.cc:393-409,452-455); two streams of data on one antenna have no defined result */
         int sounding = (m->nSS == 2 && !two_ant);
-        nl_chan_est(&s, pos + 80, m, two_ant, c);
+        if (f->sumu) {
+            /* MU frames are the one-antenna block's business (demod_impl.cc:347-379); demod2 has no such branch */
+            if (two_ant) { f->status = ORC_DROP_UNSUPPORTED; goto done; }
+            mu_chan_est(&s, pos + 80, f->mu_pos, c);
+        } else {
+            nl_chan_est(&s, pos + 80, m, two_ant, c);
+        }
         vht_sigb(&s, pos + 80 + m->nLTF * 80, m, two_ant, c, f);
-        parse_vhtb(f->sigb_bits, m);
+        if (f->sumu) {
+            if (!parse_vhtb_mu(f->sigb_bits, m)) { f->status = ORC_DROP_UNSUPPORTED; goto done; }
+        } else {
+            parse_vhtb(f->sigb_bits, m);
+        }
         if (m->len == 0 && m->nSym == 0) {
             if (two_ant) { f->status = ORC_DROP_LEN_CHECK; goto done; } /* demod2 requires len > 0 (demod2_impl.cc:159) */
             /* NDP on one antenna: raw samples of the two LTF windows (demod_impl.cc:397-398,238-249) */
@@ -1061,9 +1110,16 @@ int orc_decode(const float *llr, int nllr, int format, int len, int cr, int mcs,
 int orc_rx_frame(const float *in0_ri, const float *in1_ri, int navail, float rad, orc_frame_t *f,
                  float *llr, int llr_cap, uint8_t *out, int out_cap, int *out_len, int *n_pdu)
 {
+    return orc_rx_frame_mu(in0_ri, in1_ri, navail, rad, 0, f, llr, llr_cap, out, out_cap, out_len, n_pdu);
+}
+
+int orc_rx_frame_mu(const float *in0_ri, const float *in1_ri, int navail, float rad, int mu_pos, orc_frame_t *f,
+                    float *llr, int llr_cap, uint8_t *out, int out_cap, int *out_len, int *n_pdu)
+{
     *out_len = 0;
     *n_pdu = 0;
     if (orc_signal(in0_ri, navail, rad, f) != ORC_OK) return f->status;
+    f->mu_pos = mu_pos;
     if (orc_demod(in0_ri, in1_ri, navail, rad, f, llr, llr_cap) != ORC_OK) {
         if (f->status == ORC_NDP && out_cap >= 1027) {
             /* decode republishes the channel as a message of its own (decode_impl.cc:100-121) */

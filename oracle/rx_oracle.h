@@ -30,7 +30,7 @@ enum {
     ORC_OK = 0,
     ORC_DROP_LSIG = 1,       /* L-SIG parity/rate/length check failed (signal_impl.cc:156-160) */
     ORC_DROP_LEN_CHECK = 2,  /* HT/VHT length vs L-SIG duration sanity failed (demod_impl.cc:159,186) */
-    ORC_DROP_UNSUPPORTED = 3,/* nSS>2, MU-MIMO group id, NDP, invalid MCS: outside this build's scope */
+    ORC_DROP_UNSUPPORTED = 3,/* nSS>2, invalid MCS, MU frame on two antennas, two data streams on one antenna */
     ORC_DROP_DECODE_LIMIT = 4,/* len>4095 or trellis>32782 (decode_impl.cc:93) */
     ORC_NDP = 5              /* VHT sounding NDP on the one-antenna chain: channel message instead of a PSDU
                                 (demod_impl.cc:238-249,397-398, decode_impl.cc:100-121) */
@@ -56,6 +56,8 @@ typedef struct {
     uint8_t sig_bits[48]; /* decoded HT-SIG or VHT-SIG-A bits */
     uint8_t sigb_bits[26];
     float mu2x1chan[256]; /* NDP: the 64 + 64 raw VHT-LTF samples, re/im interleaved (demod_impl.cc:397-398) */
+    int sumu;             /* 1: VHT MU-MIMO frame (group id 1..62), cloud80211phy.h:62 */
+    int mu_pos;           /* in: this station's position in the MU group, demod::make(mupos, mugid) (demod_impl.cc:28-39) */
 } orc_frame_t;
 
 void orc_init(void);
@@ -83,6 +85,11 @@ int orc_decode(const float *llr, int nllr, int format, int len, int cr, int mcs,
 int orc_rx_frame(const float *in0_ri, const float *in1_ri, int navail, float rad,
                  orc_frame_t *f, float *llr, int llr_cap,
                  uint8_t *out, int out_cap, int *out_len, int *n_pdu);
+
+/* Same with the station's MU group position (orc_rx_frame = position 0). */
+int orc_rx_frame_mu(const float *in0_ri, const float *in1_ri, int navail, float rad, int mu_pos,
+                    orc_frame_t *f, float *llr, int llr_cap,
+                    uint8_t *out, int out_cap, int *out_len, int *n_pdu);
 
 /* Small pieces exported for table / known-answer tests. */
 void orc_sig_viterbi(const float *llr, uint8_t *bits, int trellis);      /* cloud80211phy.cc:2001-2088 */

@@ -113,6 +113,28 @@ def make_ndp():
     print("ndp", tx.shape)
 
 
+def make_mu():
+    """Two-user VHT MU-MIMO frame (group id 2, one space-time stream per user, different MCS), precoded with
+    the zero-forcing Q of the fixed 2x2 channel (rows = users) as tools/cmu_ap.py:138-151 builds it; row u of the
+    fixture is what user u's single antenna receives."""
+    mp = [mpdu_of(150, 2000), mpdu_of(220, 2001)]
+    mcs = [3, 5]
+    q = np.linalg.inv(H22)
+    q = q / np.linalg.norm(q) * np.sqrt(2.0)
+    phy = phy80211.phy80211(ifDebug=False)
+    with contextlib.redirect_stdout(io.StringIO()):
+        phy.genAmpduMu(nUser=2, bfQ=[q] * 64, groupId=2,
+                       ampdu0=mac80211.genAmpduVHT([mp[0]]), mod0=p8h.modulation(p8h.F.VHT, mcs[0], p8h.BW.BW20, 1, False),
+                       ampdu1=mac80211.genAmpduVHT([mp[1]]), mod1=p8h.modulation(p8h.F.VHT, mcs[1], p8h.BW.BW20, 1, False))
+        ss = phy.genFinalSig(multiplier=18.0, cfoHz=0.0, num=1, gap=True, gapLen=GAP)
+    tx = np.array(ss, dtype=np.complex128)
+    np.savez_compressed(
+        os.path.join(HERE, "mu_vht_2users.npz"), iq=(H22 @ tx).astype(np.complex64), sync_idx=np.int32(GAP + 160 + 16),
+        mpdu0=np.frombuffer(mp[0], dtype=np.uint8), mpdu1=np.frombuffer(mp[1], dtype=np.uint8),
+        mcs=np.array(mcs, dtype=np.int32))
+    print("mu", tx.shape)
+
+
 def make_viterbi():
     """Integer-LLR Viterbi vectors from the reference's Python decoder (ties included)."""
     rng = np.random.RandomState(7)
@@ -156,3 +178,4 @@ if __name__ == "__main__":
     make_viterbi()
     make_frames()
     make_ndp()
+    make_mu()

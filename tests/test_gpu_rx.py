@@ -17,7 +17,7 @@ def oracle_tags(f):
                 nSym=f.m.nSym, nSS=f.m.nSS)
 
 
-def run_rx(pkg, rxctx, oracle, frames, rads=None, check_llr=True, two_ant=None):
+def run_rx(pkg, rxctx, oracle, frames, rads=None, check_llr=True, two_ant=None, mu_pos=None):
     """frames: list of ([antenna arrays], sync_idx).  Compares GPU against oracle frame by frame."""
     import torch
     iq0, iq1, sync, navail = build_arena(frames)
@@ -25,7 +25,8 @@ def run_rx(pkg, rxctx, oracle, frames, rads=None, check_llr=True, two_ant=None):
         iq1 = None
     n = len(frames)
     rads = np.zeros(n, np.float32) if rads is None else np.asarray(rads, np.float32)
-    desc = rxctx.make_desc(sync, navail, rad=rads)
+    mu_pos = np.zeros(n, np.uint32) if mu_pos is None else np.asarray(mu_pos, np.uint32)
+    desc = rxctx.make_desc(sync, navail, rad=rads, mu_pos=mu_pos)
     d0 = torch.from_numpy(iq0).cuda()
     d1 = torch.from_numpy(iq1).cuda() if iq1 is not None else None
     res = rxctx.rx_batch(d0, d1, desc, n)
@@ -38,10 +39,9 @@ def run_rx(pkg, rxctx, oracle, frames, rads=None, check_llr=True, two_ant=None):
         info2, llr = rxctx.demod_batch(d0, d1, desc, n)
     results = []
     for i in range(n):
-        ref = oracle.rx_frame(iq0, iq1, int(sync[i]), float(rads[i]))
-        # the oracle sees the rest of the arena too; restrict it like the descriptor does
+        # the oracle would see the rest of the arena too; restrict it like the descriptor does
         ref = oracle.rx_frame(iq0[: int(sync[i]) + int(navail[i])], None if iq1 is None else iq1[: int(sync[i]) + int(navail[i])],
-                              int(sync[i]), float(rads[i]))
+                              int(sync[i]), float(rads[i]), mu_pos=int(mu_pos[i]))
         st = ref["status"]
         assert int(info["status"][i]) == st, (i, int(info["status"][i]), st)
         if st == 0:
@@ -252,3 +252,21 @@ def test_vht_sounding_ndp(pkg, rxctx, oracle):
     a = np.frombuffer(got[3:], np.float32)
     b = np.frombuffer(ref["blob"][3:], np.float32)
     assert np.all(np.abs(a - b) <= 1e-5 * np.abs(b).max())
+
+
+def test_vht_mu_mimo_two_users(pkg, rxctx, oracle):
+    """Two-user VHT MU-MIMO frame from the reference's Python generator (group id 2, zero-forcing precoder for the
+    fixed 2x2 channel): each station's antenna, with its group position, yields its own A-MPDU
+    (lib/demod_impl.cc:347-379, lib/cloud80211phy.cc:1170-1192).  Two antennas: demod2 has no MU branch -> dropped."""
+    from util import golden_mu
+    g = golden_mu()
+    rng = np.random.default_rng(41)
+    noisy = awgn(g["iq"], 32.0, rng).astype(np.complex64)
+    s = g["sync_idx"]
+    frames = [([g["iq"][0]], s), ([g["iq"][1]], s), ([noisy[0]], s), ([noisy[1]], s)]
+    r = run_rx(pkg, rxctx, oracle, frames, mu_pos=[0, 1, 0, 1])
+    for k, ref in enumerate(r):
+        assert ref["status"] == 0 and ref["frame"].sumu == 1 and ref["frame"].m.mcs == g["mcs"][k % 2]
+        assert [p["mpdu"] for p in ref["pdus"]] == [g["mpdus"][k % 2]]
+    r2 = run_rx(pkg, rxctx, oracle, [([g["iq"][0], g["iq"][1]], s)], check_llr=False)
+    assert r2[0]["status"] == 3 and r2[0]["n_pdu"] == 0

@@ -25,6 +25,12 @@ def golden_ndp():
     return dict(iq=z["iq"], sync_idx=int(z["sync_idx"]), rad=float(z["rad"]))
 
 
+def golden_mu():
+    z = np.load(os.path.join(GOLDEN, "mu_vht_2users.npz"))
+    return dict(iq=z["iq"], sync_idx=int(z["sync_idx"]), mpdus=[z["mpdu0"].tobytes(), z["mpdu1"].tobytes()],
+                mcs=[int(v) for v in z["mcs"]])
+
+
 def ref_fixture_mpdu():
     with open(os.path.join(GOLDEN, "ref_fixture_mpdu.hex")) as fh:
         return bytes.fromhex(fh.read().strip())
