@@ -371,6 +371,7 @@ bool rx::process(bool final)
         d.rad = t.rad;
         d.snr = t.snr;
         d.rssi = t.rssi;
+        d.mu_pos = (uint32_t)d_muPos;
         pd.push_back(d);
         pidx.push_back(j);
     }
@@ -419,6 +420,7 @@ bool rx::process(bool final)
         d.rad = t.rad;
         d.snr = t.snr;
         d.rssi = t.rssi;
+        d.mu_pos = (uint32_t)d_muPos;
         fd.push_back(d);
         d_cursor = t.pos + span;
         done = j + 1;
@@ -515,6 +517,7 @@ bool capture_rx::flush()
     int nf = 0;
     if (gr80211_copy_h2d(c, diq0, d_hold[0].data(), n * sizeof(gr_complex), nullptr) != GR80211_OK ||
         (d_nrx == 2 && gr80211_copy_h2d(c, diq1, d_hold[1].data(), n * sizeof(gr_complex), nullptr) != GR80211_OK) ||
+        gr80211_set_mu_pos(c, d_muPos) != GR80211_OK ||
         gr80211_rx_capture(c, diq0, diq1, n, dout, OUT_STRIDE, dlen, dnp, max_frames, nullptr, &nf, nullptr) != GR80211_OK) {
         d_err = d_gpu.error();
         return false;

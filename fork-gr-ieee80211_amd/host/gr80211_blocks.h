@@ -145,6 +145,8 @@ public:
                      gr_vector_void_star &output_items) override;
     bool flush() override;
 
+    // this station's position in VHT MU groups: the mupos argument of ieee80211::demod::make (lib/demod_impl.cc:28-39)
+    void set_mu_pos(int pos) { d_muPos = pos ? 1 : 0; }
     uint64_t triggers_seen() const { return d_nTrig; }
     uint64_t frames_decoded() const { return d_nFrames; }
     uint64_t pdus_published() const { return d_nPdu; }
@@ -160,6 +162,7 @@ private:
         int status, nsamp;
     };
     int d_nrx, d_batch;
+    int d_muPos = 0;
     gpu_session d_gpu;
     std::vector<gr_complex> d_hold[2];  // samples not yet released, both antennas
     uint64_t d_base = 0;                // absolute item index of d_hold[*][0]
@@ -185,12 +188,14 @@ public:
                      gr_vector_void_star &output_items) override;
     bool flush() override;
 
+    void set_mu_pos(int pos) { d_muPos = pos ? 1 : 0; }
     uint64_t frames_decoded() const { return d_nFrames; }
     uint64_t pdus_published() const { return d_nPdu; }
 
 private:
     capture_rx(int n_rx, int device);
     int d_nrx;
+    int d_muPos = 0;
     gpu_session d_gpu;
     std::vector<gr_complex> d_hold[2];
     uint64_t d_nFrames = 0, d_nPdu = 0;
