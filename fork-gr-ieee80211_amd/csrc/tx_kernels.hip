@@ -101,7 +101,8 @@ __host__ __device__ bool tx_mod(int fmt, int mcs, int nss, int len, TxMod &m)
     const int num[4] = {1, 2, 3, 5}, den[4] = {2, 3, 4, 6};
     m.fmt = fmt;
     m.mcs = mcs;
-    if (len < 1 || len > GR80211_MAX_PSDU) return false;
+    // length 0 = VHT null data packet: training and SIG fields only (tools/phy80211.py:160-175)
+    if (len < 0 || len > GR80211_MAX_PSDU || (len == 0 && fmt != GR80211_F_VHT)) return false;
     if (fmt == GR80211_F_L) {
         if (mcs < 0 || mcs > 7) return false;
         m.nss = 1;
@@ -127,10 +128,10 @@ __host__ __device__ bool tx_mod(int fmt, int mcs, int nss, int len, TxMod &m)
     m.ncbps = m.ncbpss * m.nss;
     m.ndbps = m.ncbps * num[m.cr] / den[m.cr];
     m.nltf = fmt == GR80211_F_L ? 0 : m.nss == 1 ? 1 : 2;
-    m.nsym = (8 * len + 16 + 6 + m.ndbps - 1) / m.ndbps;
+    m.nsym = len == 0 ? 0 : (8 * len + 16 + 6 + m.ndbps - 1) / m.ndbps;
     m.psdu = len;
     m.npad_eof = 0;
-    if (fmt == GR80211_F_VHT) {
+    if (fmt == GR80211_F_VHT && len > 0) {
         m.psdu = (m.nsym * m.ndbps - 16 - 6) / 8;
         m.npad_eof = (m.psdu - len) / 4;
     }
@@ -202,7 +203,8 @@ __global__ __launch_bounds__(64 * TX_WAVES) void k_tx(const uint8_t *__restrict_
 
     // ---- SIG field bits (LSB = first transmitted bit) -------------------------------------------------
     // VHT-SIG-B: length in 4-byte units (17 bits) + 3 reserved ones; its CRC-8 rides in the service field.
-    const unsigned sigb = vht ? (((unsigned)(d.psdu_len + 3) / 4) & 0x1ffff) | (7u << 17) : 0u;
+    // (a null data packet carries the fixed pattern of IEEE 802.11-2016 table 21-15 instead)
+    const unsigned sigb = !vht ? 0u : d.psdu_len == 0 ? 0x422E0u : (((unsigned)(d.psdu_len + 3) / 4) & 0x1ffff) | (7u << 17);
     const int sigb_crc = vht ? crc8_bits(sigb, 20) : 0;
     if (tid == 0) {
         const int rate_bits[8] = {0xB, 0xF, 0xA, 0xE, 0x9, 0xD, 0x8, 0xC};  // R1..R4, R1 first

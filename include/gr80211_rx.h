@@ -108,7 +108,8 @@ typedef struct {
     uint64_t out_off;  /* sample index in the output arena(s) where the frame (its L-STF) starts */
     uint32_t psdu_off; /* byte offset of the PSDU in d_psdu: the MPDU (legacy, HT) or the A-MPDU with its
                           delimiters (VHT), FCS included */
-    int32_t psdu_len;  /* bytes, 1..4095 (VHT: APEP length; padding to the symbol boundary is added) */
+    int32_t psdu_len;  /* bytes, 1..4095 (VHT: APEP length; padding to the symbol boundary is added; VHT with 0 =
+                          null data packet, the sounding frame without a data field) */
     int32_t format;    /* GR80211_F_* */
     int32_t mcs;       /* legacy 0..7, HT 0..15 (8..15 = two streams), VHT 0..8 */
     int32_t nss;       /* VHT: 1 or 2 space-time streams; ignored otherwise */

@@ -50,3 +50,23 @@ def test_host_blocks_library_loads():
     ctypes.CDLL(os.path.join(d, "libgr80211_host.so"))
     p = subprocess.run([os.path.join(d, "gr80211_pump")], capture_output=True, text=True, timeout=60)
     assert p.returncode == 2 and "usage" in p.stderr
+
+
+def test_tx_frame_lengths_match_generator(pkg):
+    """gr80211_tx_samples is host arithmetic (no GPU): the frame lengths equal the numpy generator's bookkeeping,
+    which test_txgen.py pins to the reference generator's waveforms; unsupported combinations give -1."""
+    lib = pkg.load_library()
+    tx = pkg.txgen
+    for fmt, mcss, nsss in ((0, range(8), (1,)), (1, range(16), (1,)), (2, range(9), (1, 2))):
+        for mcs in mcss:
+            for nss in nsss:
+                for ln in (1, 2, 13, 100, 1000, 1500, 4095):
+                    m = tx.Mod(fmt, mcs, nss).set_len(ln)
+                    want = m.n_samples() if m.lsig_len <= 4095 else -1
+                    assert lib.gr80211_tx_samples(fmt, mcs, nss, ln) == want, (fmt, mcs, nss, ln)
+    for bad in ((0, 8, 1, 100), (1, 16, 1, 100), (2, 9, 1, 100), (2, 0, 3, 100), (3, 0, 1, 100), (0, 0, 1, 0), (1, 3, 1, 0), (0, 0, 1, 4096)):
+        assert lib.gr80211_tx_samples(*bad) == -1, bad
+    assert lib.gr80211_tx_samples(2, 0, 2, 0) == 880 and lib.gr80211_tx_samples(2, 0, 1, 0) == 800
+    for bad in ():
+        assert lib.gr80211_tx_samples(*bad) == -1, bad
+    assert ctypes.sizeof(ctypes.c_char * pkg.rx.TX_DESC_DTYPE.itemsize) == 40

@@ -21,6 +21,7 @@ def run_tx(pkg, rxctx, jobs, gap=64):
     for i, j in enumerate(jobs):
         ns = rxctx.tx_samples(j["fmt"], j["mcs"], j.get("nss", 1), len(j["psdu"]))
         assert ns > 0, j
+        blob += b"\0" if not j["psdu"] else b""   # keep the byte arena non-empty
         d[i]["out_off"], d[i]["psdu_off"], d[i]["psdu_len"] = pos, len(blob), len(j["psdu"])
         d[i]["format"], d[i]["mcs"], d[i]["nss"] = j["fmt"], j["mcs"], j.get("nss", 1)
         d[i]["scale"], d[i]["cfo_rad"], d[i]["scrambler"] = j.get("scale", 1.0), j.get("cfo_rad", 0.0), j.get("scrambler", 93)
@@ -88,6 +89,18 @@ def test_tx_equals_numpy_generator_every_mcs(pkg, rxctx):
         assert err < TOL * 4, (j["fmt"], j["mcs"], j["nss"], len(j["psdu"]), err)
         if w.shape[0] == 1:
             assert not g[1].any()
+
+
+def test_tx_null_data_packet(pkg, rxctx, oracle):
+    """VHT NDP with two space-time streams: equals the Python generator's waveform (fixture seen through the fixed
+    2x2 channel), and the one-antenna receiver answers it with the channel message."""
+    from util import golden_ndp
+    g = golden_ndp()
+    got = run_tx(pkg, rxctx, [dict(fmt=2, mcs=0, nss=2, psdu=b"", scale=12.0 * np.sqrt(2.0))])[0]
+    assert got.shape[1] == 880 == rxctx.tx_samples(2, 0, 2, 0)
+    ref = g["iq"][:, 400:400 + 880]
+    assert np.abs(H22 @ got.astype(np.complex128) - ref).max() < TOL * 12 * 4
+    assert rxctx.tx_samples(0, 0, 1, 0) == -1 and rxctx.tx_samples(1, 0, 1, 0) == -1
 
 
 def test_tx_cfo_and_multi_subframe(pkg, rxctx):
