@@ -120,7 +120,7 @@ int finish_timing(gr80211_ctx *c, hipStream_t s)
 
 // Shared tail: schedule -> (demod) -> viterbi -> traceback.
 int run_decode_stages(gr80211_ctx *c, hipStream_t s, int n, bool from_iq, const void *d_iq0, const void *d_iq1,
-                      const gr80211_frame_desc *d_desc, const float *d_llr_in, uint8_t *d_out, int out_stride,
+                      uint64_t arena_len, const gr80211_frame_desc *d_desc, const float *d_llr_in, uint8_t *d_out, int out_stride,
                       int32_t *d_out_len, int32_t *d_n_pdu, uint8_t *d_bits, int bits_stride, bool decode,
                       const float **llr_used, uint64_t *llr_floats)
 {
@@ -146,7 +146,7 @@ int run_decode_stages(gr80211_ctx *c, hipStream_t s, int n, bool from_iq, const 
     const float *llr = d_llr_in;
     if (from_iq) {
         if ((rc = ensure(c, c->llr, (size_t)(tot.llr_floats + 64) * sizeof(float)))) return rc;
-        launch_demod(d_iq0, d_iq1, d_desc, n, info, c->chan1.p, c->chan2.p, (float *)c->llr.p, s);
+        launch_demod(d_iq0, d_iq1, arena_len, d_desc, n, info, c->chan1.p, c->chan2.p, (float *)c->llr.p, s);
         llr = (const float *)c->llr.p;
     }
     if (llr_used) *llr_used = llr;
@@ -154,7 +154,7 @@ int run_decode_stages(gr80211_ctx *c, hipStream_t s, int n, bool from_iq, const 
     mark(c, 3, s);
     if (decode) {
         launch_clear_outputs(d_out_len, d_n_pdu, n, s);
-        if (from_iq && !d_iq1) launch_ndp_emit(d_iq0, d_desc, n, info, d_out, out_stride, d_out_len, d_n_pdu, s);
+        if (from_iq && !d_iq1) launch_ndp_emit(d_iq0, arena_len, d_desc, n, info, d_out, out_stride, d_out_len, d_n_pdu, s);
         if (tot.n_groups > 0) {
             if ((rc = ensure(c, c->dec, (size_t)(tot.dec_words + 128) * sizeof(uint32_t)))) return rc;
             if ((rc = ensure(c, c->bitsw, (size_t)(tot.bits_words + 64) * sizeof(uint32_t)))) return rc;
@@ -352,7 +352,7 @@ int gr80211_rx_batch(gr80211_ctx *c, const void *d_iq0, const void *d_iq1, uint6
     const gr80211_frame_desc *dd = nullptr;
     int rc = front_end(c, s, d_iq0, d_iq1, arena_len, desc, n, flags, &dd);
     if (rc) return rc;
-    rc = run_decode_stages(c, s, n, true, d_iq0, d_iq1, dd, nullptr, d_out, out_stride, d_out_len, d_n_pdu, nullptr, 0,
+    rc = run_decode_stages(c, s, n, true, d_iq0, d_iq1, arena_len, dd, nullptr, d_out, out_stride, d_out_len, d_n_pdu, nullptr, 0,
                            true, nullptr, nullptr);
     if (rc) return rc;
     if (d_info)
@@ -419,7 +419,7 @@ int gr80211_rx_capture(gr80211_ctx *c, const void *d_iq0, const void *d_iq1, uin
     if (d_desc_out)
         HIP_TRY(c, hipMemcpyAsync(d_desc_out, d_sel, (size_t)nf * sizeof(gr80211_frame_desc), hipMemcpyDeviceToDevice, s));
     if ((rc = front_end(c, s, d_iq0, d_iq1, n_samples, d_sel, nf, GR80211_FLAG_DESC_ON_DEVICE, &dd))) return rc;
-    rc = run_decode_stages(c, s, nf, true, d_iq0, d_iq1, dd, nullptr, d_out, out_stride, d_out_len, d_n_pdu, nullptr, 0,
+    rc = run_decode_stages(c, s, nf, true, d_iq0, d_iq1, n_samples, dd, nullptr, d_out, out_stride, d_out_len, d_n_pdu, nullptr, 0,
                            true, nullptr, nullptr);
     if (rc) return rc;
     return finish_timing(c, s);
@@ -457,7 +457,7 @@ int gr80211_demod_batch(gr80211_ctx *c, const void *d_iq0, const void *d_iq1, ui
     const gr80211_frame_desc *dd = nullptr;
     int rc = front_end(c, s, d_iq0, d_iq1, arena_len, desc, n, flags, &dd);
     if (rc) return rc;
-    rc = run_decode_stages(c, s, n, true, d_iq0, d_iq1, dd, nullptr, nullptr, 0, nullptr, nullptr, nullptr, 0, false,
+    rc = run_decode_stages(c, s, n, true, d_iq0, d_iq1, arena_len, dd, nullptr, nullptr, 0, nullptr, nullptr, nullptr, 0, false,
                            d_llr, llr_floats);
     if (rc) return rc;
     if (d_info)
@@ -492,9 +492,9 @@ int gr80211_decode_batch(gr80211_ctx *c, const float *d_llr, uint64_t llr_floats
     if ((rc = stage_desc(c, s, desc, (size_t)n * sizeof(gr80211_dec_desc), flags, c->ddesc, &dd))) return rc;
     if ((rc = ensure(c, c->info, (size_t)n * sizeof(gr80211_frame_info)))) return rc;
     mark(c, 0, s);
-    launch_desc_to_info((const gr80211_dec_desc *)dd, n, (gr80211_frame_info *)c->info.p, s);
+    launch_desc_to_info((const gr80211_dec_desc *)dd, n, llr_floats, (gr80211_frame_info *)c->info.p, s);
     mark(c, 1, s);
-    rc = run_decode_stages(c, s, n, false, nullptr, nullptr, nullptr, d_llr, d_out, out_stride, d_out_len, d_n_pdu,
+    rc = run_decode_stages(c, s, n, false, nullptr, nullptr, 0, nullptr, d_llr, d_out, out_stride, d_out_len, d_n_pdu,
                            d_bits, bits_stride, true, nullptr, nullptr);
     if (rc) return rc;
     return finish_timing(c, s);

@@ -34,11 +34,11 @@ int upload_tables(const Tables &t);
 
 void launch_preamble(const void *iq0, const void *iq1, uint64_t arena_len, const gr80211_frame_desc *desc,
                      int n, gr80211_frame_info *info, void *chan1, void *chan2, hipStream_t s);
-void launch_desc_to_info(const gr80211_dec_desc *desc, int n, gr80211_frame_info *info, hipStream_t s);
+void launch_desc_to_info(const gr80211_dec_desc *desc, int n, uint64_t llr_floats, gr80211_frame_info *info, hipStream_t s);
 void launch_schedule(gr80211_frame_info *info, int n, int assign_llr, int32_t *slot_frame, int slot_cap,
                      GroupInfo *groups, int group_cap, SchedTotals *totals, uint32_t *ws, unsigned long long *blk_llr,
                      hipStream_t s);
-void launch_demod(const void *iq0, const void *iq1, const gr80211_frame_desc *desc, int n,
+void launch_demod(const void *iq0, const void *iq1, uint64_t arena_len, const gr80211_frame_desc *desc, int n,
                   const gr80211_frame_info *info, const void *chan1, const void *chan2, float *llr,
                   hipStream_t s);
 void launch_viterbi(const float *llr, const gr80211_frame_info *info, const int32_t *slot_frame,
@@ -52,8 +52,9 @@ void launch_decode(const float *llr, const gr80211_frame_info *info, const int32
 #ifdef GR80211_TIMELINE
 int read_timeline(unsigned long long *dst, int n_groups);
 #endif
-void launch_ndp_emit(const void *iq0, const gr80211_frame_desc *desc, int n, const gr80211_frame_info *info, uint8_t *out,
-                     int out_stride, int32_t *out_len, int32_t *n_pdu, hipStream_t s);
+void launch_ndp_emit(const void *iq0, uint64_t arena_len, const gr80211_frame_desc *desc, int n,
+                     const gr80211_frame_info *info, uint8_t *out, int out_stride, int32_t *out_len, int32_t *n_pdu,
+                     hipStream_t s);
 void launch_clear_outputs(int32_t *out_len, int32_t *n_pdu, int n, hipStream_t s);
 
 }  // namespace gr80211

@@ -303,6 +303,18 @@ __device__ __forceinline__ void zf2(c32 F1, c32 F2, const c32 (&h)[4], const c32
 // =========================================================================================
 constexpr int CH2 = 520;  // per-frame 2x2 channel block: H[64][4], Hinv[64][4], pilot refs [2][4]
 
+// The part of the arena a descriptor may touch: its claim cut to the arena (a descriptor that starts outside the
+// arena gets nothing).  Every kernel that reads samples derives its bounds from here.
+__device__ __forceinline__ int frame_window(const gr80211_frame_desc &d, uint64_t arena_len, uint64_t *start)
+{
+    uint64_t so = d.sync_off;
+    uint64_t navail64 = d.n_avail;
+    if (so >= arena_len) { so = 0; navail64 = 0; }
+    if (so + navail64 > arena_len) navail64 = arena_len - so;
+    *start = so;
+    return (int)(navail64 > 0x7fffffffull ? 0x7fffffffull : navail64);
+}
+
 __global__ __launch_bounds__(64) void k_preamble(const c32 *__restrict__ iq0, const c32 *__restrict__ iq1,
                                                  uint64_t arena_len, const gr80211_frame_desc *__restrict__ descs,
                                                  int n, gr80211_frame_info *__restrict__ info,
@@ -322,11 +334,8 @@ __global__ __launch_bounds__(64) void k_preamble(const c32 *__restrict__ iq0, co
     __shared__ double s_red[64];
 
     const gr80211_frame_desc d = descs[f];
-    uint64_t so = d.sync_off;
-    uint64_t navail64 = d.n_avail;
-    if (so >= arena_len) { so = 0; navail64 = 0; }
-    if (so + navail64 > arena_len) navail64 = arena_len - so;
-    const int navail = (int)(navail64 > 0x7fffffffull ? 0x7fffffffull : navail64);
+    uint64_t so;
+    const int navail = frame_window(d, arena_len, &so);
     const float rad = d.rad;
     const c32 *in0 = iq0 + so;
     const c32 *in1 = iq1 ? iq1 + so : nullptr;
@@ -676,7 +685,8 @@ finish:
 // =========================================================================================
 // k_desc_to_info: decode-only entry, tags -> frame records
 // =========================================================================================
-__global__ void k_desc_to_info(const gr80211_dec_desc *__restrict__ desc, int n, gr80211_frame_info *__restrict__ info)
+__global__ void k_desc_to_info(const gr80211_dec_desc *__restrict__ desc, int n, unsigned long long llr_floats,
+                               gr80211_frame_info *__restrict__ info)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -685,7 +695,8 @@ __global__ void k_desc_to_info(const gr80211_dec_desc *__restrict__ desc, int n,
     fi.status = GR80211_ST_OK;
     fi.format = d.format; fi.len = d.len; fi.cr = d.cr; fi.mcs = d.mcs; fi.ampdu = d.ampdu;
     fi.trellis = d.trellis; fi.total = d.n_llr; fi.llr_off = d.llr_off; fi.slot = -1;
-    if (d.cr < 0 || d.cr > 3 || d.n_llr < 0 || d.llr_off < 0) {
+    if (d.cr < 0 || d.cr > 3 || d.n_llr < 0 || d.llr_off < 0 ||
+        (unsigned long long)d.llr_off + (unsigned long long)d.n_llr > llr_floats) {  // soft bits outside the arena
         fi.status = GR80211_ST_DROP_UNSUPPORTED;
     } else if (d.trellis > 0 && d.trellis <= GR80211_MAX_TRELLIS) {
         // soft bits the trellis consumes; with fewer the reference block would wait for more input
@@ -998,6 +1009,7 @@ __device__ __forceinline__ void flush_stage(const float *stage, float *dst, int 
 }
 
 __global__ __launch_bounds__(64 * DEMOD_WAVES) void k_demod(const c32 *__restrict__ iq0, const c32 *__restrict__ iq1,
+                                                            uint64_t arena_len,
                                                             const gr80211_frame_desc *__restrict__ descs, int n,
                                                             const gr80211_frame_info *__restrict__ info,
                                                             const c32 *__restrict__ chan1, const c32 *__restrict__ chan2,
@@ -1014,11 +1026,13 @@ __global__ __launch_bounds__(64 * DEMOD_WAVES) void k_demod(const c32 *__restric
     float *stage = s_stage[wave];
     const gr80211_frame_info fi = info[f];
     const gr80211_frame_desc d = descs[f];
-    const c32 *in0 = iq0 + d.sync_off;
-    const c32 *in1 = iq1 ? iq1 + d.sync_off : nullptr;
+    uint64_t so;
+    const int navail = frame_window(d, arena_len, &so);
+    const c32 *in0 = iq0 + so;
+    const c32 *in1 = iq1 ? iq1 + so : nullptr;
     const float rad = d.rad;
     int nvalid = fi.nsamp;
-    if (nvalid > (int)d.n_avail - 224) nvalid = (int)d.n_avail - 224;
+    if (nvalid > navail - 224) nvalid = navail - 224;
 
     const int fmt = fi.format, nss = fi.nSS, nb = fi.nBPSCS, ncbps = fi.nCBPS, mod = fi.mod;
     const bool legacy = fmt == GR80211_F_L;
@@ -1583,7 +1597,8 @@ __global__ __launch_bounds__(64) void k_decode(const float *__restrict__ llr, co
 // (lib/demod_impl.cc:397-398: copies of sig1[8..72) and sig1[88..152) of the samples after VHT-STF).
 // One wave per frame, lane = sample of each window.
 // =========================================================================================
-__global__ __launch_bounds__(256) void k_ndp_emit(const c32 *__restrict__ iq0, const gr80211_frame_desc *__restrict__ descs,
+__global__ __launch_bounds__(256) void k_ndp_emit(const c32 *__restrict__ iq0, uint64_t arena_len,
+                                                  const gr80211_frame_desc *__restrict__ descs,
                                                   int n, const gr80211_frame_info *__restrict__ info,
                                                   uint8_t *__restrict__ out, int out_stride, int32_t *__restrict__ out_len,
                                                   int32_t *__restrict__ n_pdu)
@@ -1596,9 +1611,11 @@ __global__ __launch_bounds__(256) void k_ndp_emit(const c32 *__restrict__ iq0, c
     if (out_stride < NBYTES + 3) return;  // no room: nothing is published, as for any PDU that does not fit
     const int lane = threadIdx.x & 63;
     const gr80211_frame_desc d = descs[f];
-    const c32 *in0 = iq0 + d.sync_off;
+    uint64_t so;
+    const int navail = frame_window(d, arena_len, &so);
+    const c32 *in0 = iq0 + so;
     int nvalid = fi.nsamp;
-    if (nvalid > (int)d.n_avail - 224) nvalid = (int)d.n_avail - 224;
+    if (nvalid > navail - 224) nvalid = navail - 224;
     uint8_t *o = out + (size_t)f * out_stride;
     for (int w = 0; w < 2; w++) {
         const c32 v = load_samp(in0, fi.data_off + w * 80 + SHIFT + lane, nvalid, d.rad);
@@ -1635,9 +1652,9 @@ void launch_preamble(const void *iq0, const void *iq1, uint64_t arena_len, const
     hipLaunchKernelGGL(k_preamble, dim3(n), dim3(64), 0, s, (const c32 *)iq0, (const c32 *)iq1, arena_len, desc, n,
                        info, (c32 *)chan1, (c32 *)chan2);
 }
-void launch_desc_to_info(const gr80211_dec_desc *desc, int n, gr80211_frame_info *info, hipStream_t s)
+void launch_desc_to_info(const gr80211_dec_desc *desc, int n, uint64_t llr_floats, gr80211_frame_info *info, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_desc_to_info, dim3((n + 255) / 256), dim3(256), 0, s, desc, n, info);
+    hipLaunchKernelGGL(k_desc_to_info, dim3((n + 255) / 256), dim3(256), 0, s, desc, n, (unsigned long long)llr_floats, info);
 }
 void launch_schedule(gr80211_frame_info *info, int n, int assign_llr, int32_t *slot_frame, int slot_cap,
                      GroupInfo *groups, int group_cap, SchedTotals *totals, uint32_t *ws, unsigned long long *blk_llr,
@@ -1653,10 +1670,10 @@ void launch_schedule(gr80211_frame_info *info, int n, int assign_llr, int32_t *s
                        slot_frame, groups, totals);
     hipLaunchKernelGGL(k_sched_groups, dim3(1), dim3(1024), 0, s, groups, totals);
 }
-void launch_demod(const void *iq0, const void *iq1, const gr80211_frame_desc *desc, int n,
+void launch_demod(const void *iq0, const void *iq1, uint64_t arena_len, const gr80211_frame_desc *desc, int n,
                   const gr80211_frame_info *info, const void *chan1, const void *chan2, float *llr, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_demod, dim3(n), dim3(256), 0, s, (const c32 *)iq0, (const c32 *)iq1, desc, n, info,
+    hipLaunchKernelGGL(k_demod, dim3(n), dim3(256), 0, s, (const c32 *)iq0, (const c32 *)iq1, arena_len, desc, n, info,
                        (const c32 *)chan1, (const c32 *)chan2, llr);
 }
 void launch_viterbi(const float *llr, const gr80211_frame_info *info, const int32_t *slot_frame,
@@ -1678,10 +1695,11 @@ void launch_decode(const float *llr, const gr80211_frame_info *info, const int32
     hipLaunchKernelGGL(k_decode, dim3(n_groups), dim3(64), 0, s, llr, info, slot_frame, groups, n_groups, dec, bitsw,
                        out, out_stride, out_len, n_pdu, bits_out, bits_stride);
 }
-void launch_ndp_emit(const void *iq0, const gr80211_frame_desc *desc, int n, const gr80211_frame_info *info, uint8_t *out,
-                     int out_stride, int32_t *out_len, int32_t *n_pdu, hipStream_t s)
+void launch_ndp_emit(const void *iq0, uint64_t arena_len, const gr80211_frame_desc *desc, int n,
+                     const gr80211_frame_info *info, uint8_t *out, int out_stride, int32_t *out_len, int32_t *n_pdu,
+                     hipStream_t s)
 {
-    hipLaunchKernelGGL(k_ndp_emit, dim3((n + 3) / 4), dim3(256), 0, s, (const c32 *)iq0, desc, n, info, out, out_stride,
+    hipLaunchKernelGGL(k_ndp_emit, dim3((n + 3) / 4), dim3(256), 0, s, (const c32 *)iq0, arena_len, desc, n, info, out, out_stride,
                        out_len, n_pdu);
 }
 void launch_clear_outputs(int32_t *out_len, int32_t *n_pdu, int n, hipStream_t s)

@@ -270,3 +270,32 @@ def test_vht_mu_mimo_two_users(pkg, rxctx, oracle):
         assert [p["mpdu"] for p in ref["pdus"]] == [g["mpdus"][k % 2]]
     r2 = run_rx(pkg, rxctx, oracle, [([g["iq"][0], g["iq"][1]], s)], check_llr=False)
     assert r2[0]["status"] == 3 and r2[0]["n_pdu"] == 0
+
+
+def test_descriptors_beyond_the_arena_read_nothing(pkg, rxctx):
+    """Descriptors on the device are not validated by the host: one that points past the arena, or claims more
+    samples than the arena holds, must be cut to the arena by every kernel (no out-of-bounds read), and the good
+    frame beside them still decodes."""
+    import torch
+    tx = pkg.txgen
+    rng = np.random.default_rng(91)
+    fr, mp = make_noisy(tx, rng, 2, 5, 1, 300, 35.0)
+    sig = fr[0][0]
+    arena = torch.from_numpy(sig).cuda()
+    n = len(sig)
+    sync = np.array([fr[1], fr[1], n + 5000, n - 100, 2 ** 40], np.uint64)
+    navail = np.array([n - fr[1], 0xFFFFFFFF, 4000, 0xFFFFFFFF, 4000], np.uint32)
+    desc = rxctx.to_device(rxctx.make_desc(sync, navail))
+    res = rxctx.rx_batch(arena, None, desc, 5)
+    rxctx.sync()
+    info = res["info"].cpu().numpy().view(pkg.rx.FRAME_INFO_DTYPE)
+    n_pdu = res["n_pdu"].cpu().numpy()
+    assert list(n_pdu[:2]) == [1, 1] and rxctx.pdus_of(res, 0)[0]["mpdu"] == mp and rxctx.pdus_of(res, 1)[0]["mpdu"] == mp
+    assert list(info["status"][2:]) == [1, 1, 1] and not n_pdu[2:].any()
+    # decode-only entry: soft-bit runs outside the LLR arena are refused per frame
+    llr = torch.zeros(1000, dtype=torch.float32, device="cuda")
+    dd = np.zeros(2, dtype=pkg.rx.DEC_DESC_DTYPE)
+    dd["llr_off"], dd["n_llr"], dd["trellis"], dd["len"] = [900, 0], [200, 96], [100, 46], [10, 1]
+    r = rxctx.decode_batch(llr, rxctx.to_device(dd), 2)
+    rxctx.sync()
+    assert not r["n_pdu"].cpu().numpy().any()
