@@ -34,6 +34,7 @@ struct gr80211_ctx {
     uint32_t mu_pos = 0;  // MU group position written into the descriptors frame detection makes
     bool profiling = false;
     bool split_decode = false;  // GR80211_SPLIT_DECODE=1: forward pass and traceback as two kernels
+    int group_waves = -1;       // GR80211_GROUP_WAVES=1|2|4: wavefronts per decoder group (-1: by batch size)
     hipEvent_t ev[7] = {};
     float ms[6] = {};
 };
@@ -158,7 +159,17 @@ int run_decode_stages(gr80211_ctx *c, hipStream_t s, int n, bool from_iq, const 
         if (tot.n_groups > 0) {
             if ((rc = ensure(c, c->dec, (size_t)(tot.dec_words + 128) * sizeof(uint32_t)))) return rc;
             if ((rc = ensure(c, c->bitsw, (size_t)(tot.bits_words + 64) * sizeof(uint32_t)))) return rc;
-            if (c->split_decode) {
+            // a batch of few groups leaves SIMDs idle for a whole trellis: share each group among 2 or 4 waves
+            int gw = c->group_waves;
+            if (gw != 1 && gw != 2 && gw != 4) gw = tot.n_groups <= 256 ? 4 : tot.n_groups <= 512 ? 2 : 1;
+            if (gw > 1) {
+                launch_viterbi_split(gw, llr, info, (const int32_t *)c->slot_frame.p, (const GroupInfo *)c->groups.p,
+                                     tot.n_groups, (uint32_t *)c->dec.p, s);
+                mark(c, 4, s);
+                launch_traceback((const uint32_t *)c->dec.p, info, (const int32_t *)c->slot_frame.p,
+                                 (const GroupInfo *)c->groups.p, tot.n_groups, (uint32_t *)c->bitsw.p, d_out,
+                                 out_stride, d_out_len, d_n_pdu, d_bits, bits_stride, s);
+            } else if (c->split_decode) {
                 launch_viterbi(llr, info, (const int32_t *)c->slot_frame.p, (const GroupInfo *)c->groups.p,
                                tot.n_groups, (uint32_t *)c->dec.p, s);
                 mark(c, 4, s);
@@ -279,6 +290,7 @@ int gr80211_create(gr80211_ctx **out, int device)
     gr80211_ctx *c = new gr80211_ctx();
     c->device = device;
     if (const char *e = getenv("GR80211_SPLIT_DECODE")) c->split_decode = e[0] == '1';
+    if (const char *e = getenv("GR80211_GROUP_WAVES")) c->group_waves = atoi(e);
     {
         std::lock_guard<std::mutex> lk(g_upload_mutex);
         if (!g_uploaded[device]) {

@@ -17,6 +17,7 @@
 // operation order so that soft bits agree to rounding.
 #include <utility>
 
+#include "acs_common.h"
 #include "rx_kernels.h"
 
 namespace gr80211 {
@@ -1120,25 +1121,6 @@ __global__ __launch_bounds__(64 * DEMOD_WAVES) void k_demod(const c32 *__restric
 // =========================================================================================
 // k_viterbi: lane = frame, 64 states in registers
 // =========================================================================================
-template <int KIND, int OP>
-__device__ __forceinline__ float add_tab(float m, float t0, float t1, float t01)
-{
-    // KIND 0: both soft bits present; 1: second erased (t1 = 0); 2: first erased (t0 = 0).
-    // Adding the table entry 0.0f leaves a metric unchanged, so those adds are dropped.
-    if constexpr (KIND == 0) {
-        if constexpr (OP == 0) return m;
-        else if constexpr (OP == 1) return m + t1;
-        else if constexpr (OP == 2) return m + t0;
-        else return m + t01;
-    } else if constexpr (KIND == 1) {
-        if constexpr (OP == 0 || OP == 1) return m;
-        else return m + t0;
-    } else {
-        if constexpr (OP == 0 || OP == 2) return m;
-        else return m + t1;
-    }
-}
-
 // Four state updates (states N, N+8, N+16, N+24) written phase by phase (adds, subtracts, maxima, decision shifts) so that no
 // instruction sits next to the one it depends on: on gfx950 a dependent VALU pair costs ~9.5 cycles
 // against ~4.3 for independent issue from one wave.
@@ -1195,16 +1177,6 @@ __device__ __forceinline__ void acs_step(const float (&m)[64], float (&o)[64], f
 // Bit position of state n's survivor bit in the 64-bit word {w1:w0} of its step.
 __device__ __forceinline__ int dec_bit(int n) { return n ^ 7; }
 
-// Puncture patterns (lib/cloud80211phy.cc:1857-1860): P trellis steps consume COLS soft bits.
-template <int CR> struct Rate;
-template <> struct Rate<CR_12> { static constexpr int P = 1, COLS = 2, NPER = 32; };
-template <> struct Rate<CR_23> { static constexpr int P = 2, COLS = 3, NPER = 20; };
-template <> struct Rate<CR_34> { static constexpr int P = 3, COLS = 4, NPER = 16; };
-template <> struct Rate<CR_56> { static constexpr int P = 5, COLS = 6, NPER = 10; };
-// Step ps of a period: kind 0 = both soft bits present, 1 = second erased, 2 = first erased.
-constexpr int step_kind(int cr, int ps) { return (cr == CR_12 || ps == 0) ? 0 : (ps & 1) ? 1 : 2; }
-constexpr int step_col(int ps) { return ps == 0 ? 0 : ps + 1; }
-
 // Step S (0 .. 2P-1) of a pair of puncture periods whose soft bits start at c.  Even steps go from
 // A to B, odd steps back, so a pair of periods always starts and ends in A.
 template <int CR, int S>
@@ -1236,7 +1208,6 @@ __device__ __forceinline__ void two_periods(float (&A)[64], float (&B)[64], cons
     (step_pair<CR, U>(A, B, c, dp), ...);
 }
 
-constexpr int TILE_STRIDE = 65;
 
 template <int CR>
 __device__ __forceinline__ void viterbi_group(const float *__restrict__ llr, unsigned long long mybase, int myn,

@@ -174,3 +174,69 @@ def test_linearity_property_full_size(pkg, rxctx, oracle):
         ref = oracle.decode(f["llr"], f["fmt"], f["len"], f["cr"], f["mcs"], f["ampdu"], f["trellis"])
         ln = int(res["out_len"][i].item())
         assert bytes(res["out"][i, :ln].cpu().numpy()) == ref["blob"]
+
+
+@pytest.fixture(scope="module")
+def ctx_by_waves(pkg):
+    """Contexts pinned to 1, 2 and 4 wavefronts per decoder group (by default the library chooses by batch size,
+    so the small batches of these tests would all take the four-wave path)."""
+    import os
+    made = {}
+    old = os.environ.get("GR80211_GROUP_WAVES")
+    try:
+        for w in (1, 2, 4):
+            os.environ["GR80211_GROUP_WAVES"] = str(w)
+            made[w] = pkg.RxContext(0)
+    finally:
+        if old is None:
+            os.environ.pop("GR80211_GROUP_WAVES", None)
+        else:
+            os.environ["GR80211_GROUP_WAVES"] = old
+    yield made
+    for c in made.values():
+        c.close()
+
+
+@pytest.mark.parametrize("waves", [1, 2, 4])
+def test_each_group_width_against_oracle(pkg, ctx_by_waves, oracle, waves):
+    """Ragged lengths, all four code rates, integer LLRs with many ties: every way of spreading a group over
+    wavefronts gives the oracle's bits and PDUs."""
+    tx = pkg.txgen
+    rng = np.random.default_rng(17)
+    frames = []
+    for k in range(200):
+        cr = k % 4
+        fmt = (0, 1, 2)[k % 3]
+        frames.append(coded_frame(tx, rng, fmt, cr, int(rng.integers(20, 520)), mcs=k % 8, snr_scale=1.5, noise=1.2,
+                                  integer=(k % 2 == 0)))
+    run_and_compare(pkg, ctx_by_waves[waves], oracle, frames)
+
+
+def test_group_widths_agree_bit_for_bit(pkg, ctx_by_waves):
+    """A few thousand noisy frames (many groups, partly filled last groups per rate): survivor words written by 1, 2
+    or 4 waves per group lead to identical decoded bits and PDU slots."""
+    import torch
+    tx = pkg.txgen
+    rx = pkg.rx
+    rng = np.random.default_rng(18)
+    base = [coded_frame(tx, rng, (0, 1, 2)[k % 3], k % 4, int(rng.integers(30, 700)), mcs=k % 8, snr_scale=1.0, noise=1.0)
+            for k in range(48)]
+    n = 3000
+    desc = np.zeros(n, dtype=rx.DEC_DESC_DTYPE)
+    parts, off = [], 0
+    for i in range(n):
+        f = base[i % len(base)]
+        llr = f["llr"] + (0.7 * rng.standard_normal(len(f["llr"]))).astype(np.float32)
+        desc[i] = (off, len(llr), f["fmt"], f["len"], f["cr"], f["mcs"], f["ampdu"], f["trellis"], 0)
+        parts.append(llr)
+        off += len(llr)
+    llr = torch.from_numpy(np.concatenate(parts)).cuda()
+    got = {}
+    for w, c in ctx_by_waves.items():
+        r = c.decode_batch(llr, desc, n, want_bits=True, out_stride=768, bits_stride=768)
+        c.sync()
+        got[w] = (r["out"].cpu().numpy(), r["out_len"].cpu().numpy(), r["n_pdu"].cpu().numpy(), r["bits"].cpu().numpy())
+    assert 0 < int(got[1][2].sum()) < n   # some frames fail the FCS, some pass
+    for w in (2, 4):
+        for a, b in zip(got[1], got[w]):
+            assert np.array_equal(a, b), w
