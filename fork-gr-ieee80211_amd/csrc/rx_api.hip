@@ -161,7 +161,7 @@ int run_decode_stages(gr80211_ctx *c, hipStream_t s, int n, bool from_iq, const 
             if ((rc = ensure(c, c->bitsw, (size_t)(tot.bits_words + 64) * sizeof(uint32_t)))) return rc;
             // a batch of few groups leaves SIMDs idle for a whole trellis: share each group among 2 or 4 waves
             int gw = c->group_waves;
-            if (gw != 1 && gw != 2 && gw != 4) gw = tot.n_groups <= 256 ? 4 : tot.n_groups <= 512 ? 2 : 1;
+            if (gw != 1 && gw != 2 && gw != 4) gw = tot.n_groups <= 512 ? 4 : 1;
             if (gw > 1) {
                 launch_viterbi_split(gw, llr, info, (const int32_t *)c->slot_frame.p, (const GroupInfo *)c->groups.p,
                                      tot.n_groups, (uint32_t *)c->dec.p, s);
