@@ -34,7 +34,7 @@ struct gr80211_ctx {
     uint32_t mu_pos = 0;  // MU group position written into the descriptors frame detection makes
     bool profiling = false;
     bool split_decode = false;  // GR80211_SPLIT_DECODE=1: forward pass and traceback as two kernels
-    int group_waves = -1;       // GR80211_GROUP_WAVES=1|2|4: wavefronts per decoder group (-1: by batch size)
+    int group_waves = -1;       // GR80211_GROUP_WAVES=1|4: wavefronts per decoder group (-1: by batch size)
     hipEvent_t ev[7] = {};
     float ms[6] = {};
 };
@@ -159,11 +159,11 @@ int run_decode_stages(gr80211_ctx *c, hipStream_t s, int n, bool from_iq, const 
         if (tot.n_groups > 0) {
             if ((rc = ensure(c, c->dec, (size_t)(tot.dec_words + 128) * sizeof(uint32_t)))) return rc;
             if ((rc = ensure(c, c->bitsw, (size_t)(tot.bits_words + 64) * sizeof(uint32_t)))) return rc;
-            // a batch of few groups leaves SIMDs idle for a whole trellis: share each group among 2 or 4 waves
+            // a batch of few groups leaves SIMDs idle for a whole trellis: share each group among four waves
             int gw = c->group_waves;
-            if (gw != 1 && gw != 2 && gw != 4) gw = tot.n_groups <= 512 ? 4 : 1;
+            if (gw != 1 && gw != 4) gw = tot.n_groups <= 640 ? 4 : 1;
             if (gw > 1) {
-                launch_viterbi_split(gw, llr, info, (const int32_t *)c->slot_frame.p, (const GroupInfo *)c->groups.p,
+                launch_viterbi_split(llr, info, (const int32_t *)c->slot_frame.p, (const GroupInfo *)c->groups.p,
                                      tot.n_groups, (uint32_t *)c->dec.p, s);
                 mark(c, 4, s);
                 launch_traceback((const uint32_t *)c->dec.p, info, (const int32_t *)c->slot_frame.p,
