@@ -232,8 +232,10 @@ int gr80211_copy_d2h(gr80211_ctx *ctx, void *h_dst, const void *d_src, size_t by
 /*
  * Timing of the last batch call, measured with HIP events on the stream the kernels ran on.
  * ms[0]=preamble, [1]=schedule, [2]=demod, [3]=decode (Viterbi forward pass + traceback + assembly, one kernel),
- * [4]=0 (traceback + assembly alone when the environment variable GR80211_SPLIT_DECODE=1 selects the two-kernel
- * form, [3] then being the forward pass alone), [5]=whole call.
+ * [4]=0, [5]=whole call.  Batches of at most 640 decoder groups (about 41 000 frames of one code rate) run the
+ * forward pass with four wavefronts per group and the traceback as a second kernel: [3] is then the forward pass
+ * and [4] the traceback + assembly (the environment variables GR80211_GROUP_WAVES=1|4 and GR80211_SPLIT_DECODE=1
+ * force either form for experiments).
  * Only recorded when profiling is switched on (costs one stream synchronisation per call).
  */
 int gr80211_set_profiling(gr80211_ctx *ctx, int on);
