@@ -31,6 +31,7 @@ struct gr80211_ctx {
     Buf tx_desc;
     uint32_t *det_totals_h = nullptr;  // pinned
     SchedTotals *totals_h = nullptr;  // pinned
+    int ampdu_strict = 0;  // de-aggregate A-MPDUs by the standard's rules instead of the reference's
     uint32_t mu_pos = 0;  // MU group position written into the descriptors frame detection makes
     bool profiling = false;
     bool split_decode = false;  // GR80211_SPLIT_DECODE=1: forward pass and traceback as two kernels
@@ -168,19 +169,19 @@ int run_decode_stages(gr80211_ctx *c, hipStream_t s, int n, bool from_iq, const 
                 mark(c, 4, s);
                 launch_traceback((const uint32_t *)c->dec.p, info, (const int32_t *)c->slot_frame.p,
                                  (const GroupInfo *)c->groups.p, tot.n_groups, (uint32_t *)c->bitsw.p, d_out,
-                                 out_stride, d_out_len, d_n_pdu, d_bits, bits_stride, s);
+                                 out_stride, d_out_len, d_n_pdu, d_bits, bits_stride, c->ampdu_strict, s);
             } else if (c->split_decode) {
                 launch_viterbi(llr, info, (const int32_t *)c->slot_frame.p, (const GroupInfo *)c->groups.p,
                                tot.n_groups, (uint32_t *)c->dec.p, s);
                 mark(c, 4, s);
                 launch_traceback((const uint32_t *)c->dec.p, info, (const int32_t *)c->slot_frame.p,
                                  (const GroupInfo *)c->groups.p, tot.n_groups, (uint32_t *)c->bitsw.p, d_out,
-                                 out_stride, d_out_len, d_n_pdu, d_bits, bits_stride, s);
+                                 out_stride, d_out_len, d_n_pdu, d_bits, bits_stride, c->ampdu_strict, s);
             } else {
                 // one kernel: the timing slot of the forward pass then covers the traceback as well
                 launch_decode(llr, info, (const int32_t *)c->slot_frame.p, (const GroupInfo *)c->groups.p,
                               tot.n_groups, (uint32_t *)c->dec.p, (uint32_t *)c->bitsw.p, d_out, out_stride,
-                              d_out_len, d_n_pdu, d_bits, bits_stride, s);
+                              d_out_len, d_n_pdu, d_bits, bits_stride, c->ampdu_strict, s);
                 mark(c, 4, s);
             }
         } else {
@@ -571,6 +572,13 @@ int gr80211_set_mu_pos(gr80211_ctx *c, int mu_pos)
 {
     if (!c || mu_pos < 0 || mu_pos > 1) return GR80211_ERR_ARG;
     c->mu_pos = (uint32_t)mu_pos;
+    return GR80211_OK;
+}
+
+int gr80211_set_ampdu_strict(gr80211_ctx *c, int on)
+{
+    if (!c) return GR80211_ERR_ARG;
+    c->ampdu_strict = on != 0;
     return GR80211_OK;
 }
 

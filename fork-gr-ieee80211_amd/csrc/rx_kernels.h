@@ -45,14 +45,14 @@ void launch_viterbi(const float *llr, const gr80211_frame_info *info, const int3
                     const GroupInfo *groups, int n_groups, uint32_t *dec, hipStream_t s);
 void launch_traceback(const uint32_t *dec, const gr80211_frame_info *info, const int32_t *slot_frame,
                       const GroupInfo *groups, int n_groups, uint32_t *bitsw, uint8_t *out, int out_stride,
-                      int32_t *out_len, int32_t *n_pdu, uint8_t *bits_out, int bits_stride, hipStream_t s);
+                      int32_t *out_len, int32_t *n_pdu, uint8_t *bits_out, int bits_stride, int strict, hipStream_t s);
 // Forward pass with four wavefronts per group, for batches too small to fill the chip with one wave per group;
 // same survivor words as launch_viterbi, to be followed by launch_traceback.
 void launch_viterbi_split(const float *llr, const gr80211_frame_info *info, const int32_t *slot_frame,
                           const GroupInfo *groups, int n_groups, uint32_t *dec, hipStream_t s);
 void launch_decode(const float *llr, const gr80211_frame_info *info, const int32_t *slot_frame,
                    const GroupInfo *groups, int n_groups, uint32_t *dec, uint32_t *bitsw, uint8_t *out, int out_stride,
-                   int32_t *out_len, int32_t *n_pdu, uint8_t *bits_out, int bits_stride, hipStream_t s);
+                   int32_t *out_len, int32_t *n_pdu, uint8_t *bits_out, int bits_stride, int strict, hipStream_t s);
 #ifdef GR80211_TIMELINE
 int read_timeline(unsigned long long *dst, int n_groups);
 #endif

@@ -1291,12 +1291,28 @@ __device__ __forceinline__ uint32_t crc_byte(uint32_t c, uint32_t byte, const ui
     return tab[(c ^ byte) & 0xff] ^ (c >> 8);
 }
 
+// A-MPDU delimiter check (IEEE 802.11-2016 9.7.1): CRC-8 of its first 16 bits in bits 16..23 (first transmitted CRC
+// bit = bit 16) and the signature 0x4E in bits 24..31.
+__device__ __forceinline__ bool delimiter_ok(uint32_t d)
+{
+    unsigned c = 0xff;
+    for (int i = 0; i < 16; i++) {
+        c <<= 1;
+        if (c & 0x100) c = (c + 1) ^ 0x06;
+        if ((d >> i) & 1u) c ^= 0x07;
+    }
+    c = 0xff - (c & 0xff);
+    unsigned r = 0;
+    for (int i = 0; i < 8; i++) r |= ((c >> (7 - i)) & 1u) << i;
+    return ((d >> 16) & 0xffu) == r && (d >> 24) == 0x4Eu;
+}
+
 // One group's traceback and packet assembly; s_crc is the CRC-32 byte table in LDS.
 __device__ __forceinline__ void traceback_group(const uint32_t *__restrict__ dec, const gr80211_frame_info *__restrict__ info,
                                                 const GroupInfo &gi, const int fr, const int lane, const uint32_t *s_crc,
                                                 uint32_t *__restrict__ bitsw, uint8_t *__restrict__ out, int out_stride,
                                                 int32_t *__restrict__ out_len, int32_t *__restrict__ n_pdu,
-                                                uint8_t *__restrict__ bits_out, int bits_stride)
+                                                uint8_t *__restrict__ bits_out, int bits_stride, int strict)
 {
     const int T = fr >= 0 ? info[fr].trellis : 0;
     uint32_t *bw = bitsw + gi.bits_off + lane;
@@ -1415,7 +1431,14 @@ __device__ __forceinline__ void traceback_group(const uint32_t *__restrict__ dec
     int eof = 0;
     int procd = 16;    // bits consumed, as tmpBitsProcd
     bool done = false;
-    if (!vht) {
+    // strict: de-aggregate by the standard's rules instead of the reference's (VHT and aggregated HT PSDUs): every
+    // delimiter is checked (CRC-8, signature) and carries its own length, the search resumes on the next 4-byte
+    // boundary after a bad one, zero-length delimiters are padding
+    const bool walk = strict && (vht || fi.ampdu);
+    const int plen = fi.len < (T - 16) / 8 ? fi.len : (T - 16) / 8;  // PSDU bytes the walk may use
+    if (walk) {
+        mlen = -1;
+    } else if (!vht) {
         if (fi.ampdu) done = true;  // HT A-MPDU: nothing published (lib/decode_impl.cc:432-435)
         mlen = fi.len; mpad = fi.len;
     } else if (procd >= T) {
@@ -1435,6 +1458,15 @@ __device__ __forceinline__ void traceback_group(const uint32_t *__restrict__ dec
         const uint32_t psdu = (Dcur >> 16) | (Dnext << 16);  // PSDU dword q = k-1
         Dcur = Dnext;
         if (done) continue;
+        if (walk && mlen < 0) {
+            const int at = 4 * (k - 1);  // byte offset of this dword in the PSDU
+            if (at + 4 > plen) { done = true; continue; }
+            if (!delimiter_ok(psdu)) continue;
+            const int l = (int)((psdu >> 4) & 0xfffu) | (vht ? (int)((psdu >> 2) & 3u) << 12 : 0);
+            if (l == 0 || at + 4 + l > plen) continue;
+            mlen = l; mpad = (l + 3) & ~3; mgot = 0; crc = 0xFFFFFFFFu;
+            continue;
+        }
         if (mlen < 0) {
             // A-MPDU delimiter: bit0 EOF, bits2-3 len[13:12], bits4-15 len[11:0] (lib/decode_impl.cc:339-358)
             procd += 32;
@@ -1473,7 +1505,9 @@ __device__ __forceinline__ void traceback_group(const uint32_t *__restrict__ dec
                 wpos += mlen + 4;
                 npdu++;
             }
-            if (vht) {
+            if (walk) {
+                mlen = -1;
+            } else if (vht) {
                 mlen = -1;
                 if (eof) done = true;
             } else {
@@ -1490,7 +1524,7 @@ __global__ __launch_bounds__(64) void k_traceback(const uint32_t *__restrict__ d
                                                   const GroupInfo *__restrict__ groups, int n_groups,
                                                   uint32_t *__restrict__ bitsw, uint8_t *__restrict__ out, int out_stride,
                                                   int32_t *__restrict__ out_len, int32_t *__restrict__ n_pdu,
-                                                  uint8_t *__restrict__ bits_out, int bits_stride)
+                                                  uint8_t *__restrict__ bits_out, int bits_stride, int strict)
 {
     const int g = blockIdx.x;
     if (g >= n_groups) return;
@@ -1500,7 +1534,7 @@ __global__ __launch_bounds__(64) void k_traceback(const uint32_t *__restrict__ d
     __syncthreads();
     const GroupInfo gi = groups[g];
     const int fr = slot_frame[g * 64 + lane];
-    traceback_group(dec, info, gi, fr, lane, s_crc, bitsw, out, out_stride, out_len, n_pdu, bits_out, bits_stride);
+    traceback_group(dec, info, gi, fr, lane, s_crc, bitsw, out, out_stride, out_len, n_pdu, bits_out, bits_stride, strict);
 }
 
 // =========================================================================================
@@ -1523,7 +1557,8 @@ __global__ __launch_bounds__(64) void k_decode(const float *__restrict__ llr, co
                                                const GroupInfo *__restrict__ groups, int n_groups,
                                                uint32_t *__restrict__ dec, uint32_t *__restrict__ bitsw,
                                                uint8_t *__restrict__ out, int out_stride, int32_t *__restrict__ out_len,
-                                               int32_t *__restrict__ n_pdu, uint8_t *__restrict__ bits_out, int bits_stride)
+                                               int32_t *__restrict__ n_pdu, uint8_t *__restrict__ bits_out, int bits_stride,
+                                               int strict)
 {
     const int g = blockIdx.x;
     if (g >= n_groups) return;
@@ -1556,7 +1591,7 @@ __global__ __launch_bounds__(64) void k_decode(const float *__restrict__ llr, co
     uint32_t *s_crc = reinterpret_cast<uint32_t *>(tile);  // the LLR tile is dead from here on
     for (int i = lane; i < 256; i += 64) s_crc[i] = c_tab.crc[i];
     __syncthreads();
-    traceback_group(dec, info, gi, fr, lane, s_crc, bitsw, out, out_stride, out_len, n_pdu, bits_out, bits_stride);
+    traceback_group(dec, info, gi, fr, lane, s_crc, bitsw, out, out_stride, out_len, n_pdu, bits_out, bits_stride, strict);
 #ifdef GR80211_TIMELINE
     if (lane == 0 && g < 8192) g_timeline[4 * g + 2] = wall_clock64();
 #endif
@@ -1654,17 +1689,17 @@ void launch_viterbi(const float *llr, const gr80211_frame_info *info, const int3
 }
 void launch_traceback(const uint32_t *dec, const gr80211_frame_info *info, const int32_t *slot_frame,
                       const GroupInfo *groups, int n_groups, uint32_t *bitsw, uint8_t *out, int out_stride,
-                      int32_t *out_len, int32_t *n_pdu, uint8_t *bits_out, int bits_stride, hipStream_t s)
+                      int32_t *out_len, int32_t *n_pdu, uint8_t *bits_out, int bits_stride, int strict, hipStream_t s)
 {
     hipLaunchKernelGGL(k_traceback, dim3(n_groups), dim3(64), 0, s, dec, info, slot_frame, groups, n_groups, bitsw,
-                       out, out_stride, out_len, n_pdu, bits_out, bits_stride);
+                       out, out_stride, out_len, n_pdu, bits_out, bits_stride, strict);
 }
 void launch_decode(const float *llr, const gr80211_frame_info *info, const int32_t *slot_frame,
                    const GroupInfo *groups, int n_groups, uint32_t *dec, uint32_t *bitsw, uint8_t *out, int out_stride,
-                   int32_t *out_len, int32_t *n_pdu, uint8_t *bits_out, int bits_stride, hipStream_t s)
+                   int32_t *out_len, int32_t *n_pdu, uint8_t *bits_out, int bits_stride, int strict, hipStream_t s)
 {
     hipLaunchKernelGGL(k_decode, dim3(n_groups), dim3(64), 0, s, llr, info, slot_frame, groups, n_groups, dec, bitsw,
-                       out, out_stride, out_len, n_pdu, bits_out, bits_stride);
+                       out, out_stride, out_len, n_pdu, bits_out, bits_stride, strict);
 }
 void launch_ndp_emit(const void *iq0, uint64_t arena_len, const gr80211_frame_desc *desc, int n,
                      const gr80211_frame_info *info, uint8_t *out, int out_stride, int32_t *out_len, int32_t *n_pdu,

@@ -61,7 +61,7 @@ EXPORTS = [
     "gr80211_create", "gr80211_destroy", "gr80211_last_error", "gr80211_sync", "gr80211_rx_batch", "gr80211_signal_batch", "gr80211_detect", "gr80211_rx_capture",
     "gr80211_demod_batch", "gr80211_decode_batch", "gr80211_dev_alloc", "gr80211_dev_free",
     "gr80211_copy_h2d", "gr80211_copy_d2h", "gr80211_set_profiling", "gr80211_last_timing",
-    "gr80211_version", "gr80211_table_checksum", "gr80211_tx_samples", "gr80211_tx_batch", "gr80211_set_mu_pos",
+    "gr80211_version", "gr80211_table_checksum", "gr80211_tx_samples", "gr80211_tx_batch", "gr80211_set_mu_pos", "gr80211_set_ampdu_strict",
 ]
 
 _lib = None
@@ -98,6 +98,7 @@ def load_library():
     L.gr80211_copy_d2h.argtypes = [vp, vp, vp, C.c_size_t, vp]
     L.gr80211_set_profiling.argtypes = [vp, C.c_int]
     L.gr80211_set_mu_pos.argtypes = [vp, C.c_int]
+    L.gr80211_set_ampdu_strict.argtypes = [vp, C.c_int]
     L.gr80211_last_timing.argtypes = [vp, C.POINTER(C.c_float), C.c_int]
     L.gr80211_tx_samples.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
     L.gr80211_tx_batch.argtypes = [vp, vp, C.c_uint64, vp, C.c_int, C.c_uint, vp, vp, C.c_uint64, vp, vp]
@@ -172,6 +173,9 @@ class RxContext:
 
     def set_mu_pos(self, pos):
         self._check(self.lib.gr80211_set_mu_pos(self.h, int(pos)), "set_mu_pos")
+
+    def set_ampdu_strict(self, on):
+        self._check(self.lib.gr80211_set_ampdu_strict(self.h, 1 if on else 0), "set_ampdu_strict")
 
     def last_timing(self):
         ms = (C.c_float * 6)()

@@ -240,13 +240,15 @@ def make_mpdu(nbytes, rng):
     return body + struct.pack("<L", zlib.crc32(body) & 0xFFFFFFFF)
 
 
-def ampdu_vht(mpdus):
-    """A-MPDU subframes: 4-byte delimiter (EOF, rsvd, len[13:12], len[11:0], CRC-8, 0x4E) + MPDU + pad to 4."""
+def ampdu_vht(mpdus, eof=None):
+    """A-MPDU subframes: 4-byte delimiter (EOF, rsvd, len[13:12], len[11:0], CRC-8, 0x4E) + MPDU + pad to 4.
+    eof: the EOF bit of every delimiter (default: set for a single-MPDU A-MPDU as VHT requires; HT delimiters
+    have it reserved = 0)."""
     out = b""
     for m in mpdus:
         ln = len(m)
         lb = [(ln >> i) & 1 for i in range(14)]
-        bits = [1 if len(mpdus) == 1 else 0, 0] + lb[12:14] + lb[0:12]
+        bits = [(1 if len(mpdus) == 1 else 0) if eof is None else eof, 0] + lb[12:14] + lb[0:12]
         bits = bits + crc8_bits(bits) + [(0x4E >> i) & 1 for i in range(8)]
         by = bytes(sum(bits[i * 8 + j] << j for j in range(8)) for i in range(4))
         pkt = by + m
@@ -255,13 +257,16 @@ def ampdu_vht(mpdus):
     return out
 
 
-def gen_frame(fmt, mcs, nss, mpdu, scrambler=93, n_mpdu_list=None):
+def gen_frame(fmt, mcs, nss, mpdu, scrambler=93, n_mpdu_list=None, ht_aggregate=False):
     """Baseband frame(s): returns (array [nss][N] complex128, Mod).  For VHT `mpdu` is wrapped into a
-    single-subframe A-MPDU (pass n_mpdu_list=[m0, m1, ...] for several subframes)."""
+    single-subframe A-MPDU (pass n_mpdu_list=[m0, m1, ...] for several subframes).  ht_aggregate: HT PSDU =
+    A-MPDU of n_mpdu_list (or [mpdu]), HT-SIG aggregation bit set."""
     m = Mod(fmt, mcs, nss)
     nss = m.nss
     if fmt == F_VHT:
         payload = ampdu_vht(n_mpdu_list if n_mpdu_list is not None else [mpdu])
+    elif fmt == F_HT and ht_aggregate:
+        payload = ampdu_vht(n_mpdu_list if n_mpdu_list is not None else [mpdu], eof=0)
     else:
         payload = mpdu
     m.set_len(len(payload))
@@ -284,7 +289,7 @@ def gen_frame(fmt, mcs, nss, mpdu, scrambler=93, n_mpdu_list=None):
     sigb_crc = [0] * 8
     if fmt == F_HT:
         b = [(mcs >> i) & 1 for i in range(7)] + [0] + [(m.psdu >> i) & 1 for i in range(16)]
-        b += [1, 1, 1, 0, 0, 0, 0, 0, 0, 0]   # smoothing, not sounding, reserved, aggregation, stbc x2, bcc, long GI, ess x2
+        b += [1, 1, 1, 1 if ht_aggregate else 0, 0, 0, 0, 0, 0, 0]   # smoothing, not sounding, reserved, aggregation, stbc x2, bcc, long GI, ess x2
         b = b + crc8_bits(b) + [0] * 6
         c = bcc_encode(b)
         for iss in range(nss):

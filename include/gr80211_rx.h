@@ -174,6 +174,16 @@ int gr80211_rx_capture(gr80211_ctx *ctx, const void *d_iq0, const void *d_iq1, u
 int gr80211_set_mu_pos(gr80211_ctx *ctx, int mu_pos);
 
 /*
+ * A-MPDU de-aggregation rule of this context.  0 (default) = the reference's: VHT delimiters are trusted unchecked
+ * and their length field is OR-accumulated from subframe to subframe, aggregated HT PSDUs publish nothing
+ * (lib/decode_impl.cc:329-435).  1 = IEEE 802.11-2016 10.13.3: every delimiter's CRC-8 and signature are checked, each
+ * carries its own length, after a bad delimiter the search resumes on the next 4-byte boundary, zero-length
+ * delimiters are padding; applies to VHT PSDUs and to HT PSDUs whose HT-SIG aggregation bit is set.  No counterpart
+ * in the reference (it lists the fix as open work).
+ */
+int gr80211_set_ampdu_strict(gr80211_ctx *ctx, int on);
+
+/*
  * signal/signal2 (and the format detection of demod/demod2) only: L-SIG decode, format detection,
  * HT-SIG / VHT-SIG-A / VHT-SIG-B decode and channel estimation of every frame, no data symbols.
  * d_info[i] receives status, L-SIG mcs/len, nsamp (the number of samples `signal` forwards after

@@ -66,6 +66,10 @@ def lib():
                                    u8, C.c_int, ip, ip]
         L.orc_rx_frame_mu.argtypes = [fp, fp, C.c_int, C.c_float, C.c_int, C.POINTER(Frame), fp, C.c_int,
                                       u8, C.c_int, ip, ip]
+        L.orc_rx_frame_ex.argtypes = [fp, fp, C.c_int, C.c_float, C.c_int, C.c_int, C.POINTER(Frame), fp, C.c_int,
+                                      u8, C.c_int, ip, ip]
+        L.orc_decode_ex.argtypes = [fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                    u8, C.c_int, ip, u8]
         L.orc_sig_viterbi.argtypes = [fp, u8, C.c_int]
         L.orc_viterbi_bits.argtypes = [fp, C.c_int, C.c_int, C.c_int, u8]
         L.orc_get_table.argtypes = [C.c_char_p, ip, C.c_int, ip]
@@ -130,20 +134,20 @@ def split_pdus(blob):
     return out
 
 
-def decode(llr, format, length, cr, mcs, ampdu, trellis, want_bits=False):
+def decode(llr, format, length, cr, mcs, ampdu, trellis, want_bits=False, strict=False):
     llr = np.ascontiguousarray(llr, dtype=np.float32)
     out = np.zeros(8192, dtype=np.uint8)
     olen = C.c_int(0)
     bits = np.zeros(max(trellis, 1) + 8, dtype=np.uint8)
-    n = lib().orc_decode(_fp(llr), len(llr), format, length, cr, mcs, ampdu, trellis,
-                         _u8(out), len(out), C.byref(olen), _u8(bits))
+    n = lib().orc_decode_ex(_fp(llr), len(llr), format, length, cr, mcs, ampdu, trellis, 1 if strict else 0,
+                            _u8(out), len(out), C.byref(olen), _u8(bits))
     res = dict(n_pdu=n, blob=bytes(out[: olen.value]), pdus=split_pdus(bytes(out[: olen.value])))
     if want_bits:
         res["bits"] = bits[:trellis].copy()
     return res
 
 
-def rx_frame(iq0, iq1, sync_idx, rad=0.0, want_llr=True, mu_pos=0):
+def rx_frame(iq0, iq1, sync_idx, rad=0.0, want_llr=True, mu_pos=0, strict=False):
     """Run signal -> demod/demod2 -> decode on one frame.
 
     iq0/iq1: complex64 capture(s) of each antenna (iq1 None for the SISO demod block);
@@ -163,8 +167,8 @@ def rx_frame(iq0, iq1, sync_idx, rad=0.0, want_llr=True, mu_pos=0):
     out = np.zeros(8192, dtype=np.uint8)
     olen = C.c_int(0)
     npdu = C.c_int(0)
-    st = lib().orc_rx_frame_mu(p0, p1, navail, np.float32(rad), int(mu_pos), C.byref(f), _fp(llr), cap,
-                               _u8(out), len(out), C.byref(olen), C.byref(npdu))
+    st = lib().orc_rx_frame_ex(p0, p1, navail, np.float32(rad), int(mu_pos), 1 if strict else 0, C.byref(f), _fp(llr),
+                               cap, _u8(out), len(out), C.byref(olen), C.byref(npdu))
     blob = bytes(out[: olen.value])
     res = dict(status=st, frame=f, n_pdu=npdu.value, blob=blob, pdus=split_pdus(blob))
     if want_llr and st == 0:

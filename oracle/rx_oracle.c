@@ -1062,9 +1062,29 @@ static int emit_pdu(const uint8_t *bitp, int format, int len, int mcs, uint8_t *
     return 1;
 }
 
-/* lib/decode_impl.cc:93-97,164-520 */
+/* A-MPDU delimiter check, IEEE 802.11-2016 9.7.1: CRC-8 over the first 16 bits, signature 0x4E. */
+static int delimiter_ok(const uint8_t *bp)
+{
+    uint8_t c[8];
+    orc_crc8_bits(bp, 16, c);
+    for (int i = 0; i < 8; i++)
+        if (c[i] != bp[16 + i]) return 0;
+    for (int i = 0; i < 8; i++)
+        if (bp[24 + i] != ((0x4E >> i) & 1)) return 0;
+    return 1;
+}
+
 int orc_decode(const float *llr, int nllr, int format, int len, int cr, int mcs, int ampdu, int trellis,
                uint8_t *out, int out_cap, int *out_len, uint8_t *bits_out)
+{
+    return orc_decode_ex(llr, nllr, format, len, cr, mcs, ampdu, trellis, 0, out, out_cap, out_len, bits_out);
+}
+
+/* lib/decode_impl.cc:93-97,164-520.  strict != 0 replaces the reference's A-MPDU walk by the standard's
+ * de-aggregation (IEEE 802.11-2016 10.13.3), which the reference does not implement: checked delimiters, each with
+ * its own length, resynchronisation on 4-byte boundaries, for VHT and for aggregated HT PSDUs. */
+int orc_decode_ex(const float *llr, int nllr, int format, int len, int cr, int mcs, int ampdu, int trellis, int strict,
+                  uint8_t *out, int out_cap, int *out_len, uint8_t *bits_out)
 {
     orc_init();
     *out_len = 0;
@@ -1075,7 +1095,21 @@ int orc_decode(const float *llr, int nllr, int format, int len, int cr, int mcs,
     descramble(w, trellis);
     if (bits_out) memcpy(bits_out, w->bits, trellis);
     int npdu = 0, pos = 0;
-    if (format == ORC_F_VHT) {
+    if (strict && (format == ORC_F_VHT || (format == ORC_F_HT && ampdu))) {
+        int plen = len < (trellis - 16) / 8 ? len : (trellis - 16) / 8;
+        int at = 0;
+        while (at + 4 <= plen) {
+            const uint8_t *bp = &w->bits[16 + 8 * at];
+            at += 4;
+            if (!delimiter_ok(bp)) continue;
+            int l = 0;
+            for (int i = 0; i < 12; i++) l |= ((int)bp[4 + i]) << i;
+            if (format == ORC_F_VHT) l |= (((int)bp[2]) << 12) | (((int)bp[3]) << 13);
+            if (l == 0 || at + l > plen) continue;
+            if (l <= ORC_MAX_PSDU) npdu += emit_pdu(&w->bits[16 + 8 * at], format, l, mcs, out, out_cap, &pos);
+            at += (l + 3) & ~3;
+        }
+    } else if (format == ORC_F_VHT) {
         /* A-MPDU walk, lib/decode_impl.cc:329-428.  tmpLen is OR-accumulated across subframes
          * exactly as the reference does (declared outside the loop, :336). */
         int procd = 16;
@@ -1116,6 +1150,12 @@ int orc_rx_frame(const float *in0_ri, const float *in1_ri, int navail, float rad
 int orc_rx_frame_mu(const float *in0_ri, const float *in1_ri, int navail, float rad, int mu_pos, orc_frame_t *f,
                     float *llr, int llr_cap, uint8_t *out, int out_cap, int *out_len, int *n_pdu)
 {
+    return orc_rx_frame_ex(in0_ri, in1_ri, navail, rad, mu_pos, 0, f, llr, llr_cap, out, out_cap, out_len, n_pdu);
+}
+
+int orc_rx_frame_ex(const float *in0_ri, const float *in1_ri, int navail, float rad, int mu_pos, int strict, orc_frame_t *f,
+                    float *llr, int llr_cap, uint8_t *out, int out_cap, int *out_len, int *n_pdu)
+{
     *out_len = 0;
     *n_pdu = 0;
     if (orc_signal(in0_ri, navail, rad, f) != ORC_OK) return f->status;
@@ -1136,7 +1176,7 @@ int orc_rx_frame_mu(const float *in0_ri, const float *in1_ri, int navail, float 
         f->status = ORC_DROP_DECODE_LIMIT;
         return f->status;
     }
-    *n_pdu = orc_decode(llr, f->total, f->m.format, f->m.len, f->m.cr, f->m.mcs, f->m.ampdu, f->trellis,
-                        out, out_cap, out_len, NULL);
+    *n_pdu = orc_decode_ex(llr, f->total, f->m.format, f->m.len, f->m.cr, f->m.mcs, f->m.ampdu, f->trellis, strict,
+                           out, out_cap, out_len, NULL);
     return f->status;
 }

@@ -81,6 +81,10 @@ int orc_demod(const float *in0_ri, const float *in1_ri, int navail, float rad,
 int orc_decode(const float *llr, int nllr, int format, int len, int cr, int mcs, int ampdu,
                int trellis, uint8_t *out, int out_cap, int *out_len, uint8_t *bits_out);
 
+/* Same with the A-MPDU rule selectable: strict != 0 = the standard's de-aggregation instead of the reference's. */
+int orc_decode_ex(const float *llr, int nllr, int format, int len, int cr, int mcs, int ampdu,
+                  int trellis, int strict, uint8_t *out, int out_cap, int *out_len, uint8_t *bits_out);
+
 /* Whole chain for one frame. */
 int orc_rx_frame(const float *in0_ri, const float *in1_ri, int navail, float rad,
                  orc_frame_t *f, float *llr, int llr_cap,
@@ -88,6 +92,10 @@ int orc_rx_frame(const float *in0_ri, const float *in1_ri, int navail, float rad
 
 /* Same with the station's MU group position (orc_rx_frame = position 0). */
 int orc_rx_frame_mu(const float *in0_ri, const float *in1_ri, int navail, float rad, int mu_pos,
+                    orc_frame_t *f, float *llr, int llr_cap,
+                    uint8_t *out, int out_cap, int *out_len, int *n_pdu);
+
+int orc_rx_frame_ex(const float *in0_ri, const float *in1_ri, int navail, float rad, int mu_pos, int strict,
                     orc_frame_t *f, float *llr, int llr_cap,
                     uint8_t *out, int out_cap, int *out_len, int *n_pdu);
 

@@ -135,6 +135,22 @@ def make_mu():
     print("mu", tx.shape)
 
 
+def make_ampdu():
+    """VHT A-MPDU with three MPDUs of different lengths (mac80211.genAmpduVHT): what a standard-conformant
+    de-aggregation must return; the reference's own receiver OR-accumulates the delimiter lengths and loses them."""
+    mps = [mpdu_of(n, 3000 + i) for i, n in enumerate((120, 333, 64))]
+    phy = phy80211.phy80211(ifDebug=False)
+    with contextlib.redirect_stdout(io.StringIO()):
+        phy.genFromAmpdu(mac80211.genAmpduVHT(mps), p8h.modulation(p8h.F.VHT, 5, p8h.BW.BW20, 1, False),
+                         vhtPartialAid=0, vhtGroupId=0)
+        ss = phy.genFinalSig(multiplier=12.0, cfoHz=0.0, num=1, gap=True, gapLen=GAP)
+    np.savez_compressed(
+        os.path.join(HERE, "ampdu_vht_3mpdu.npz"), iq=np.array(ss, dtype=np.complex128).astype(np.complex64),
+        sync_idx=np.int32(GAP + 160 + 16), lens=np.array([len(m) for m in mps], dtype=np.int32),
+        mpdus=np.frombuffer(b"".join(mps), dtype=np.uint8))
+    print("ampdu", np.array(ss).shape)
+
+
 def make_viterbi():
     """Integer-LLR Viterbi vectors from the reference's Python decoder (ties included)."""
     rng = np.random.RandomState(7)
@@ -179,3 +195,4 @@ if __name__ == "__main__":
     make_frames()
     make_ndp()
     make_mu()
+    make_ampdu()

@@ -17,7 +17,7 @@ def oracle_tags(f):
                 nSym=f.m.nSym, nSS=f.m.nSS)
 
 
-def run_rx(pkg, rxctx, oracle, frames, rads=None, check_llr=True, two_ant=None, mu_pos=None):
+def run_rx(pkg, rxctx, oracle, frames, rads=None, check_llr=True, two_ant=None, mu_pos=None, strict=False):
     """frames: list of ([antenna arrays], sync_idx).  Compares GPU against oracle frame by frame."""
     import torch
     iq0, iq1, sync, navail = build_arena(frames)
@@ -41,7 +41,7 @@ def run_rx(pkg, rxctx, oracle, frames, rads=None, check_llr=True, two_ant=None, 
     for i in range(n):
         # the oracle would see the rest of the arena too; restrict it like the descriptor does
         ref = oracle.rx_frame(iq0[: int(sync[i]) + int(navail[i])], None if iq1 is None else iq1[: int(sync[i]) + int(navail[i])],
-                              int(sync[i]), float(rads[i]), mu_pos=int(mu_pos[i]))
+                              int(sync[i]), float(rads[i]), mu_pos=int(mu_pos[i]), strict=strict)
         st = ref["status"]
         assert int(info["status"][i]) == st, (i, int(info["status"][i]), st)
         if st == 0:
@@ -299,3 +299,46 @@ def test_descriptors_beyond_the_arena_read_nothing(pkg, rxctx):
     r = rxctx.decode_batch(llr, rxctx.to_device(dd), 2)
     rxctx.sync()
     assert not r["n_pdu"].cpu().numpy().any()
+
+
+def test_ampdu_strict_deaggregation(pkg, rxctx, oracle):
+    """gr80211_set_ampdu_strict: the standard's de-aggregation instead of the reference's.  (1) A VHT A-MPDU of three
+    different lengths from the reference's Python generator: the reference rule keeps only the first MPDU (its
+    length field is OR-accumulated), the strict rule returns all three.  (2) A corrupted delimiter loses its own
+    MPDU only; the search resumes at the next valid delimiter.  (3) Aggregated HT PSDUs, which the reference does
+    not decode at all."""
+    import torch
+    from util import golden_ampdu
+    tx = pkg.txgen
+    rng = np.random.default_rng(51)
+    g = golden_ampdu()
+    strict_ctx = pkg.RxContext(0)
+    strict_ctx.set_ampdu_strict(True)
+    try:
+        frames = [([g["iq"][0]], g["sync_idx"])]
+        # (2) four MPDUs, the second delimiter damaged, through the GPU transmitter
+        ms = [tx.make_mpdu(n, rng) for n in (90, 150, 41, 260)]
+        ampdu = bytearray(tx.ampdu_vht(ms))
+        second = 4 + 92  # delimiter of the second subframe (first: 4 + 90 bytes padded to 92)
+        assert ampdu[second + 3] == 0x4E
+        ampdu[second + 1] ^= 0x10
+        d = rxctx.make_tx_desc(1)
+        ns = rxctx.tx_samples(2, 4, 1, len(ampdu))
+        d[0]["out_off"], d[0]["psdu_len"], d[0]["format"], d[0]["mcs"], d[0]["scale"] = 50, len(ampdu), 2, 4, 12.0
+        arena = torch.zeros(ns + 100, dtype=torch.complex64, device="cuda")
+        rxctx.tx_batch(torch.from_numpy(np.frombuffer(bytes(ampdu), np.uint8).copy()).cuda(), d, 1, arena)
+        frames.append(([awgn(arena.cpu().numpy(), 33.0, rng).astype(np.complex64)], 50 + 176))
+        # (3) HT A-MPDU of three MPDUs
+        hs = [tx.make_mpdu(n, rng) for n in (77, 200, 133)]
+        sig, m = tx.gen_frame(1, 5, 1, None, n_mpdu_list=hs, ht_aggregate=True)
+        ht = np.concatenate([np.zeros(40), awgn(sig[0] * 12.0, 33.0, rng), np.zeros(40)]).astype(np.complex64)
+        frames.append(([ht], 40 + 176))
+        loose = run_rx(pkg, rxctx, oracle, frames, check_llr=False)
+        tight = run_rx(pkg, strict_ctx, oracle, frames, check_llr=False, strict=True)
+        assert [p["mpdu"] for p in loose[0]["pdus"]] == g["mpdus"][:1]
+        assert [p["mpdu"] for p in tight[0]["pdus"]] == g["mpdus"]
+        assert [p["mpdu"] for p in tight[1]["pdus"]] == [ms[0], ms[2], ms[3]]
+        assert loose[2]["n_pdu"] == 0 and loose[2]["frame"].m.ampdu == 1
+        assert [p["mpdu"] for p in tight[2]["pdus"]] == hs
+    finally:
+        strict_ctx.close()

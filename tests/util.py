@@ -31,6 +31,15 @@ def golden_mu():
                 mcs=[int(v) for v in z["mcs"]])
 
 
+def golden_ampdu():
+    z = np.load(os.path.join(GOLDEN, "ampdu_vht_3mpdu.npz"))
+    raw, out, at = z["mpdus"].tobytes(), [], 0
+    for n in z["lens"]:
+        out.append(raw[at:at + int(n)])
+        at += int(n)
+    return dict(iq=z["iq"], sync_idx=int(z["sync_idx"]), mpdus=out)
+
+
 def ref_fixture_mpdu():
     with open(os.path.join(GOLDEN, "ref_fixture_mpdu.hex")) as fh:
         return bytes.fromhex(fh.read().strip())
