@@ -86,6 +86,9 @@ public:
     gpu_session(const gpu_session &) = delete;
     gpu_session &operator=(const gpu_session &) = delete;
     bool ok() const { return d_ctx != nullptr; }
+    // A-MPDU rule of every batch this session decodes: false = the reference's, true = the standard's
+    // (gr80211_set_ampdu_strict)
+    void set_ampdu_strict(bool on) { if (d_ctx) gr80211_set_ampdu_strict(d_ctx, on ? 1 : 0); }
     gr80211_ctx *ctx() const { return d_ctx; }
     void *buffer(int slot, size_t bytes);  // device buffer `slot` of at least `bytes` (contents not preserved)
     std::string error() const;
@@ -113,6 +116,7 @@ public:
                      gr_vector_void_star &output_items) override;
     bool flush() override;
 
+    void set_ampdu_strict(bool on) { d_gpu.set_ampdu_strict(on); }
     uint64_t packets_seen() const { return d_nSeen; }
     uint64_t pdus_published() const { return d_nPdu; }
 
@@ -147,6 +151,7 @@ public:
 
     // this station's position in VHT MU groups: the mupos argument of ieee80211::demod::make (lib/demod_impl.cc:28-39)
     void set_mu_pos(int pos) { d_muPos = pos ? 1 : 0; }
+    void set_ampdu_strict(bool on) { d_gpu.set_ampdu_strict(on); }
     uint64_t triggers_seen() const { return d_nTrig; }
     uint64_t frames_decoded() const { return d_nFrames; }
     uint64_t pdus_published() const { return d_nPdu; }
@@ -189,6 +194,7 @@ public:
     bool flush() override;
 
     void set_mu_pos(int pos) { d_muPos = pos ? 1 : 0; }
+    void set_ampdu_strict(bool on) { d_gpu.set_ampdu_strict(on); }
     uint64_t frames_decoded() const { return d_nFrames; }
     uint64_t pdus_published() const { return d_nPdu; }
 
