@@ -62,6 +62,14 @@ constexpr int brev6c(int v)
 }
 constexpr int LN7 = brev6c(7), LN21 = brev6c(21), LN43 = brev6c(43), LN57 = brev6c(57);
 
+// Value of lane L in every lane (v_readlane: the result is wave-uniform and costs no LDS crossbar trip).
+template <int L>
+__device__ __forceinline__ c32 lane_c(c32 v)
+{
+    return mk(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(v.x), L)),
+              __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v.y), L)));
+}
+
 __device__ __forceinline__ bool is_pilot_bin(int b) { return b == 7 || b == 21 || b == 43 || b == 57; }
 
 // Sample k of the stream `demod` sees: the samples after L-SIG, CFO-derotated by
@@ -384,7 +392,7 @@ __global__ __launch_bounds__(64) void k_preamble(const c32 *__restrict__ iq0, co
             hl = cdivf(cadd(S1, S2), ltfl * 2.0f);
             e = cdiv(SG, hl);
         }
-        const c32 e7 = shfl_c(e, LN7), e21 = shfl_c(e, LN21), e43 = shfl_c(e, LN43), e57 = shfl_c(e, LN57);
+        const c32 e7 = lane_c<LN7>(e), e21 = lane_c<LN21>(e), e43 = lane_c<LN43>(e), e57 = lane_c<LN57>(e);
         const c32 ps = cconj(cadd(cadd(csub(e7, e21), e43), e57));
         const float pa = cabs32(ps);
         if (demap >= 0) s_llr[0][demap] = cdivf(cmul(e, ps), pa).x;
@@ -414,8 +422,8 @@ __global__ __launch_bounds__(64) void k_preamble(const c32 *__restrict__ iq0, co
             e1 = cdiv(F1, hl);
             e2 = cdiv(F2, hl);
         }
-        const c32 p1 = cconj(cadd(cadd(csub(shfl_c(e1, LN7), shfl_c(e1, LN21)), shfl_c(e1, LN43)), shfl_c(e1, LN57)));
-        const c32 p2 = cconj(cadd(cadd(csub(shfl_c(e2, LN7), shfl_c(e2, LN21)), shfl_c(e2, LN43)), shfl_c(e2, LN57)));
+        const c32 p1 = cconj(cadd(cadd(csub(lane_c<LN7>(e1), lane_c<LN21>(e1)), lane_c<LN43>(e1)), lane_c<LN57>(e1)));
+        const c32 p2 = cconj(cadd(cadd(csub(lane_c<LN7>(e2), lane_c<LN21>(e2)), lane_c<LN43>(e2)), lane_c<LN57>(e2)));
         const float a1 = cabs32(p1), a2 = cabs32(p2);
         if (demap >= 0) {
             const c32 m1 = cdivf(cmul(e1, p1), a1), m2 = cdivf(cmul(e2, p2), a2);
@@ -560,7 +568,7 @@ __global__ __launch_bounds__(64) void k_preamble(const c32 *__restrict__ iq0, co
                 const c32 F1 = wave_fft64(load_samp(in0, ob + SHIFT + lane, nvalid, rad), lane);
                 c32 e = mk(0.0f, 0.0f);
                 if (nused) e = cdiv(F1, hn);
-                const c32 ps = cconj(cadd(cadd(csub(shfl_c(e, LN7), shfl_c(e, LN21)), shfl_c(e, LN43)), shfl_c(e, LN57)));
+                const c32 ps = cconj(cadd(cadd(csub(lane_c<LN7>(e), lane_c<LN21>(e)), lane_c<LN43>(e)), lane_c<LN57>(e)));
                 const float pa = cabs32(ps);
                 q0 = cdivf(cmul(e, ps), pa);
                 inted = q0.x;
@@ -570,14 +578,14 @@ __global__ __launch_bounds__(64) void k_preamble(const c32 *__restrict__ iq0, co
                 c32 s1, s2;
                 zf2(F1, F2, h, hi, s1, s2);
                 const c32 u1 = cmul(s1, pl1), u2 = cmul(s2, pl2);  // meaningful on pilot lanes
-                c32 acc = shfl_c(u1, LN7);
-                acc = csub(acc, shfl_c(u1, LN21));
-                acc = cadd(acc, shfl_c(u1, LN43));
-                acc = cadd(acc, shfl_c(u1, LN57));
-                acc = cadd(acc, shfl_c(u2, LN7));
-                acc = csub(acc, shfl_c(u2, LN21));
-                acc = cadd(acc, shfl_c(u2, LN43));
-                acc = cadd(acc, shfl_c(u2, LN57));
+                c32 acc = lane_c<LN7>(u1);
+                acc = csub(acc, lane_c<LN21>(u1));
+                acc = cadd(acc, lane_c<LN43>(u1));
+                acc = cadd(acc, lane_c<LN57>(u1));
+                acc = cadd(acc, lane_c<LN7>(u2));
+                acc = csub(acc, lane_c<LN21>(u2));
+                acc = cadd(acc, lane_c<LN43>(u2));
+                acc = cadd(acc, lane_c<LN57>(u2));
                 const c32 ps = cconj(acc);
                 const float pa = cabs32(ps);
                 q0 = cdivf(cmul(s1, ps), pa);
@@ -1066,7 +1074,7 @@ __global__ __launch_bounds__(64 * DEMOD_WAVES) void k_demod(const c32 *__restric
             const int pr = legacy ? pslot : ((pslot + sym) & 3);
             const float pv = pr == 3 ? -1.0f : 1.0f;
             const c32 u = cmulf(cmulf(e, pv), pp);
-            const c32 ps = cconj(cadd(cadd(cadd(shfl_c(u, LN7), shfl_c(u, LN21)), shfl_c(u, LN43)), shfl_c(u, LN57)));
+            const c32 ps = cconj(cadd(cadd(cadd(lane_c<LN7>(u), lane_c<LN21>(u)), lane_c<LN43>(u)), lane_c<LN57>(u)));
             const float pa = cabs32(ps);
             if (jd >= 0) put_llrs(stage, cdivf(cmul(e, ps), pa), mod, scale, nb, nax, kI, kQ);
             flush_stage(stage, out + (size_t)sym * ncbps, ncbps, lane);
@@ -1099,14 +1107,14 @@ __global__ __launch_bounds__(64 * DEMOD_WAVES) void k_demod(const c32 *__restric
             const float pv2 = vht ? (pr == 3 ? -1.0f : 1.0f) : ((pr == 1 || pr == 2) ? -1.0f : 1.0f);
             const c32 u1 = cmul(cmulf(cmulf(s1, pv1), pp), pl1);
             const c32 u2 = cmul(cmulf(cmulf(s2, pv2), pp), pl2);
-            c32 acc = shfl_c(u1, LN7);
-            acc = cadd(acc, shfl_c(u1, LN21));
-            acc = cadd(acc, shfl_c(u1, LN43));
-            acc = cadd(acc, shfl_c(u1, LN57));
-            acc = cadd(acc, shfl_c(u2, LN7));
-            acc = cadd(acc, shfl_c(u2, LN21));
-            acc = cadd(acc, shfl_c(u2, LN43));
-            acc = cadd(acc, shfl_c(u2, LN57));
+            c32 acc = lane_c<LN7>(u1);
+            acc = cadd(acc, lane_c<LN21>(u1));
+            acc = cadd(acc, lane_c<LN43>(u1));
+            acc = cadd(acc, lane_c<LN57>(u1));
+            acc = cadd(acc, lane_c<LN7>(u2));
+            acc = cadd(acc, lane_c<LN21>(u2));
+            acc = cadd(acc, lane_c<LN43>(u2));
+            acc = cadd(acc, lane_c<LN57>(u2));
             const c32 ps = cconj(acc);
             const float pa = cabs32(ps);
             if (jd >= 0) {
