@@ -536,6 +536,25 @@ int gr80211_tx_batch(gr80211_ctx *c, const uint8_t *d_psdu, uint64_t psdu_bytes,
     return GR80211_OK;
 }
 
+int gr80211_tx_mu_batch(gr80211_ctx *c, const uint8_t *d_psdu, uint64_t psdu_bytes, const gr80211_tx_mu_desc *desc, int n,
+                        unsigned flags, const void *d_q, int n_q, void *d_iq0, void *d_iq1, uint64_t arena_len,
+                        int32_t *d_n_samples, void *stream)
+{
+    if (!c) return GR80211_ERR_ARG;
+    if (n == 0) return GR80211_OK;
+    if (!d_psdu || !desc || n < 0 || !d_q || n_q < 1 || !d_iq0 || !d_iq1)
+        return fail(c, GR80211_ERR_ARG, "gr80211_tx_mu_batch: bad argument");
+    if (n > (1 << 20)) return fail(c, GR80211_ERR_ARG, "gr80211_tx_mu_batch: at most 1048576 frames per call");
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = pick(c, stream);
+    const void *dd = nullptr;
+    int rc = stage_desc(c, s, desc, (size_t)n * sizeof(gr80211_tx_mu_desc), flags, c->tx_desc, &dd);
+    if (rc) return rc;
+    launch_tx_mu(d_psdu, psdu_bytes, (const gr80211_tx_mu_desc *)dd, n, d_q, n_q, d_iq0, d_iq1, arena_len, d_n_samples, s);
+    HIP_TRY(c, hipGetLastError());
+    return GR80211_OK;
+}
+
 void *gr80211_dev_alloc(gr80211_ctx *c, size_t bytes)
 {
     if (!c) return nullptr;

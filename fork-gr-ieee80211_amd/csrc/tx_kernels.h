@@ -21,4 +21,7 @@ int upload_tx_tables(const Tables &t);
 void launch_tx(const uint8_t *psdu, uint64_t psdu_bytes, const gr80211_tx_desc *desc, int n, void *iq0, void *iq1,
                uint64_t arena_len, int32_t *n_samples, hipStream_t s);
 
+void launch_tx_mu(const uint8_t *psdu, uint64_t psdu_bytes, const gr80211_tx_mu_desc *desc, int n, const void *qmat, int n_q,
+                  void *iq0, void *iq1, uint64_t arena_len, int32_t *n_samples, hipStream_t s);
+
 }  // namespace gr80211

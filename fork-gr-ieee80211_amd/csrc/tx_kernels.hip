@@ -174,6 +174,60 @@ __device__ __forceinline__ void emit(c32 x, int lane, c32 *body, c32 *out, int s
     __builtin_amdgcn_wave_barrier();
 }
 
+// The scrambled data field of one PSDU as a packed bit string: bits[w + 1] = bits 32w .. 32w+31 (bits[0] = 0 is the
+// encoder's initial state).  Service field (16 zeros; VHT: the SIG-B CRC in its second byte), PSDU bytes, VHT EOF
+// padding delimiters, zero padding; xor the scrambler sequence; six tail bits forced to zero at tail_at.
+__device__ __forceinline__ void build_bits(uint32_t *bits, const uint8_t *src, int apep, int npad_eof, int nbits, int tail_at,
+                                           int sigb_crc, int scrambler, int tid)
+{
+    // scrambler x^7 + x^4 + 1: its 127-bit output period for this seed, twice over in 192 bits
+    unsigned long long e0 = 0, e1 = 0, e2 = 0;
+    {
+        unsigned st = (unsigned)scrambler;
+        unsigned long long lo = 0, hi = 0;
+        for (int i = 0; i < 127; i++) {
+            const unsigned fb = ((st >> 6) ^ (st >> 3)) & 1u;
+            if (i < 64) lo |= (unsigned long long)fb << i;
+            else hi |= (unsigned long long)fb << (i - 64);
+            st = ((st << 1) & 0x7eu) | fb;
+        }
+        e0 = lo;
+        e1 = hi | (lo << 63);
+        e2 = (lo >> 1) | (hi << 63);
+    }
+    const int nwords = (nbits + 31) / 32;
+    const unsigned eof_delim = 0x4E000001u | ((unsigned)crc8_bits(1ull, 16) << 16);
+    for (int w = tid; w < nwords; w += 64 * TX_WAVES) {
+        unsigned data = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int j = 4 * w - 2 + k;  // PSDU byte that occupies bits 8k .. 8k+7 of this word
+            unsigned by = 0;
+            if (j == -1) by = (unsigned)sigb_crc;  // VHT: second service byte carries the SIG-B CRC
+            else if (j >= 0 && j < apep) by = src[j];
+            else if (j >= apep && j < apep + 4 * npad_eof) by = (eof_delim >> (8 * ((j - apep) & 3))) & 0xff;
+            data |= by << (8 * k);
+        }
+        const int p = (32 * w) % 127;
+        const unsigned long long a = p < 64 ? e0 : e1, b = p < 64 ? e1 : e2;
+        const int sh = p & 63;
+        const unsigned seq = (unsigned)(sh ? (a >> sh) | (b << (64 - sh)) : a);
+        unsigned v = data ^ seq;
+        // tail bits are zero after scrambling; VHT scrambles nbits - 6 bits and appends the tail
+        const int lo = tail_at - 32 * w;
+        if (lo < 32 && lo > -6) {
+            const unsigned long long msk = 0x3full << (lo + 6);
+            v &= ~(unsigned)(msk >> 6);
+        }
+        if (32 * w + 32 > nbits) v &= (nbits & 31) ? ((1u << (nbits & 31)) - 1u) : 0xffffffffu;
+        bits[w + 1] = v;
+    }
+    if (tid == 0) {
+        bits[0] = 0;
+        bits[nwords + 1] = 0;
+    }
+}
+
 }  // namespace
 
 __global__ __launch_bounds__(64 * TX_WAVES) void k_tx(const uint8_t *__restrict__ psdu, unsigned long long psdu_bytes,
@@ -228,56 +282,9 @@ __global__ __launch_bounds__(64 * TX_WAVES) void k_tx(const uint8_t *__restrict_
         s_sig[3] = sigb;
     }
 
-    // ---- scrambled data bits as a packed string ---------------------------------------------------------
-    // scrambler x^7 + x^4 + 1: its 127-bit output period for this seed, twice over in 192 bits
-    unsigned long long e0 = 0, e1 = 0, e2 = 0;
-    {
-        unsigned st = (unsigned)d.scrambler;
-        unsigned long long lo = 0, hi = 0;
-        for (int i = 0; i < 127; i++) {
-            const unsigned fb = ((st >> 6) ^ (st >> 3)) & 1u;
-            if (i < 64) lo |= (unsigned long long)fb << i;
-            else hi |= (unsigned long long)fb << (i - 64);
-            st = ((st << 1) & 0x7eu) | fb;
-        }
-        e0 = lo;
-        e1 = hi | (lo << 63);
-        e2 = (lo >> 1) | (hi << 63);
-    }
+    // ---- scrambled data bits as a packed string
     const int nbits = m.nsym * m.ndbps;
-    const int nwords = (nbits + 31) / 32;
-    const int apep = d.psdu_len;
-    const int tail_at = vht ? nbits - 6 : 16 + 8 * apep;
-    const unsigned eof_delim = 0x4E000001u | ((unsigned)crc8_bits(1ull, 16) << 16);
-    for (int w = tid; w < nwords; w += 64 * TX_WAVES) {
-        unsigned data = 0;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int j = 4 * w - 2 + k;  // PSDU byte that occupies bits 8k .. 8k+7 of this word
-            unsigned by = 0;
-            if (j == -1) by = (unsigned)sigb_crc;  // VHT: second service byte carries the SIG-B CRC
-            else if (j >= 0 && j < apep) by = src[j];
-            else if (j >= apep && j < apep + 4 * m.npad_eof) by = (eof_delim >> (8 * ((j - apep) & 3))) & 0xff;
-            data |= by << (8 * k);
-        }
-        const int p = (32 * w) % 127;
-        const unsigned long long a = p < 64 ? e0 : e1, b = p < 64 ? e1 : e2;
-        const int sh = p & 63;
-        const unsigned seq = (unsigned)(sh ? (a >> sh) | (b << (64 - sh)) : a);
-        unsigned v = data ^ seq;
-        // tail bits are zero after scrambling; VHT scrambles nbits - 6 bits and appends the tail
-        const int lo = tail_at - 32 * w;
-        if (lo < 32 && lo > -6) {
-            const unsigned long long msk = 0x3full << (lo + 6);
-            v &= ~(unsigned)(msk >> 6);
-        }
-        if (32 * w + 32 > nbits) v &= (nbits & 31) ? ((1u << (nbits & 31)) - 1u) : 0xffffffffu;
-        s_bits[w + 1] = v;
-    }
-    if (tid == 0) {
-        s_bits[0] = 0;
-        s_bits[nwords + 1] = 0;
-    }
+    build_bits(s_bits, src, d.psdu_len, m.npad_eof, nbits, vht ? nbits - 6 : 16 + 8 * d.psdu_len, sigb_crc, d.scrambler, tid);
     __syncthreads();
 
     // ---- per-lane constants ---------------------------------------------------------------------------
@@ -424,6 +431,216 @@ void launch_tx(const uint8_t *psdu, uint64_t psdu_bytes, const gr80211_tx_desc *
     if (n <= 0) return;
     hipLaunchKernelGGL(k_tx, dim3(n), dim3(64 * TX_WAVES), 0, s, psdu, (unsigned long long)psdu_bytes, desc, n, (c32 *)iq0,
                        (c32 *)iq1, (unsigned long long)arena_len, n_samples);
+}
+
+// =========================================================================================
+// k_tx_mu: two-user VHT MU-MIMO frames (tools/phy80211.py genAmpduMu 183-224, 596-662, 815-838): one space-time
+// stream per user, each with its own A-MPDU, MCS and VHT-SIG-B; from the VHT-STF on, every tone of the two streams
+// is mixed onto the two transmit chains by the steering matrix Q of that tone (the streams' cyclic shifts are
+// applied before Q, as phase ramps).  The legacy part and VHT-SIG-A go out unsteered like a two-chain frame.
+// =========================================================================================
+__global__ __launch_bounds__(64 * TX_WAVES) void k_tx_mu(const uint8_t *__restrict__ psdu, unsigned long long psdu_bytes,
+                                                         const gr80211_tx_mu_desc *__restrict__ descs, int n,
+                                                         const c32 *__restrict__ qmat, int n_q, c32 *__restrict__ iq0,
+                                                         c32 *__restrict__ iq1, unsigned long long arena_len,
+                                                         int32_t *__restrict__ n_samples)
+{
+    const int f = blockIdx.x;
+    if (f >= n) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ uint32_t s_bits[2][TX_BIT_WORDS];
+    __shared__ uint32_t s_sig[5];  // [0] L-SIG, [1..2] VHT-SIG-A, [3..4] VHT-SIG-B of user 0 / 1
+    __shared__ c32 s_body[TX_WAVES][64];
+    const gr80211_tx_mu_desc d = descs[f];
+    TxMod mu[2];
+    bool ok = d.group_id >= 1 && d.group_id <= 62 && d.q_index >= 0 && d.q_index < n_q && d.scrambler >= 1 && d.scrambler <= 127;
+    int nsym = 0;
+    for (int u = 0; u < 2; u++) {
+        ok = ok && d.psdu_len[u] >= 4 && (d.psdu_len[u] & 3) == 0 && tx_mod(GR80211_F_VHT, d.mcs[u], 1, d.psdu_len[u], mu[u]);
+        ok = ok && (unsigned long long)d.psdu_off[u] + (unsigned long long)d.psdu_len[u] <= psdu_bytes;
+        if (ok && mu[u].nsym > nsym) nsym = mu[u].nsym;
+    }
+    // frame timing of a two-stream VHT frame with the longer user's symbol count
+    const int txus = 20 + 8 + 4 + 4 * 2 + 4 + 4 * nsym;
+    const int lsig_len = (txus - 20) / 4 * 3 - 3;
+    const int nsamp = 400 + 160 + 80 + 160 + 80 + 80 * nsym;
+    ok = ok && lsig_len <= 4095 && d.out_off + (unsigned long long)nsamp <= arena_len;
+    // both users are padded to the common symbol count: their PSDUs must still fit what the receiver accepts
+    for (int u = 0; u < 2; u++) ok = ok && (nsym * mu[u].ndbps - 22) / 8 <= GR80211_MAX_PSDU + 3;
+    if (!ok) {
+        if (tid == 0 && n_samples) n_samples[f] = -1;
+        return;
+    }
+    if (tid == 0 && n_samples) n_samples[f] = nsamp;
+
+    // ---- SIG bits.  MU VHT-SIG-B (20 MHz): length / 4 in 16 bits, MCS in 4 bits; its CRC-8 goes to the service field
+    unsigned sigb[2];
+    int sigb_crc[2];
+    for (int u = 0; u < 2; u++) {
+        sigb[u] = ((unsigned)(d.psdu_len[u] / 4) & 0xffffu) | ((unsigned)d.mcs[u] << 16);
+        sigb_crc[u] = crc8_bits(sigb[u], 20);
+    }
+    if (tid == 0) {
+        unsigned ls = 0xBu | ((unsigned)lsig_len << 5);
+        ls |= (unsigned)(__popc(ls) & 1) << 17;
+        s_sig[0] = ls;
+        // A1: bw = 0, reserved 1, stbc 0, group id, one space-time stream for users 0 and 1, none for 2 and 3,
+        //     txop_ps 0, reserved 1.  A2: sgi 0 0, coding of user 0 = BCC, ldpc extra 0, coding of user 1 = BCC,
+        //     two absent users reserved 1 1, reserved 1, reserved 1, reserved 1
+        unsigned long long sg = (1ull << 2) | ((unsigned long long)d.group_id << 4) | (1ull << 10) | (1ull << 13) | (1ull << 23);
+        sg |= 0x1full << 29;
+        sg |= (unsigned long long)crc8_bits(sg, 34) << 34;
+        s_sig[1] = (uint32_t)sg;
+        s_sig[2] = (uint32_t)(sg >> 32);
+        s_sig[3] = sigb[0];
+        s_sig[4] = sigb[1];
+    }
+    for (int u = 0; u < 2; u++) {
+        const int nbits = nsym * mu[u].ndbps;
+        const int psdu_on_air = (nbits - 22) / 8;
+        build_bits(s_bits[u], psdu + d.psdu_off[u], d.psdu_len[u], (psdu_on_air - d.psdu_len[u]) / 4, nbits, nbits - 6,
+                   sigb_crc[u], d.scrambler, tid);
+    }
+    __syncthreads();
+
+    // ---- per-lane constants
+    const int kt = bin_to_tone(lane);
+    const int pil = pilot_index(lane);
+    const int d_l = c_tx.data_idx_l[lane], d_nl = c_tx.data_idx_nl[lane];
+    const float ltf_l = c_tx.ltf_l[lane], ltf_nl = c_tx.ltf_nl[lane];
+    float stf = 0.0f;
+    if (kt != 0 && (kt & 3) == 0 && kt >= -24 && kt <= 24) {
+        const int sgn[13] = {1, -1, 1, -1, -1, 1, 0, -1, -1, 1, 1, 1, 1};
+        stf = 0.70710678118654752f * (float)sgn[(kt + 24) / 4];
+    }
+    const float base_pil[4] = {1.0f, 1.0f, 1.0f, -1.0f};
+    uint16_t tpos[2][8];
+    unsigned gsel[2] = {0, 0};
+    float qnorm[2];
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        const int nb = mu[u].nbpscs;
+        const int didx = nb == 1 ? 0 : nb == 2 ? 1 : nb == 4 ? 2 : nb == 6 ? 3 : 4;
+        const int P = mu[u].cr == CR_12 ? 1 : mu[u].cr == CR_23 ? 2 : mu[u].cr == CR_34 ? 3 : 5;
+        const int K = P + 1;
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            tpos[u][b] = 0;
+            if (d_nl >= 0 && b < nb) {
+                const int c = c_tx.deint_nl[didx][d_nl * nb + b];
+                const int q = c / K, r = c % K;
+                tpos[u][b] = (uint16_t)(P * q + (r < 2 ? 0 : r - 1));
+                gsel[u] |= (unsigned)(r & 1) << b;
+            }
+        }
+        qnorm[u] = nb == 1 ? 1.0f : nb == 2 ? 0.70710678118654752f : nb == 4 ? 0.31622776601683794f
+                   : nb == 6 ? 0.15430334996209191f : 0.076696498884737041f;
+    }
+    // steering matrix of this lane's tone: chain r gets q[r][0] * stream 0 + q[r][1] * stream 1
+    const c32 *qm = qmat + ((size_t)d.q_index * 64 + lane) * 4;
+    const c32 q00 = qm[0], q01 = qm[1], q10 = qm[2], q11 = qm[3];
+    // -400 ns on the second stream = phase +2 pi 8 k / 64 on tone k
+    const float csc[8] = {1.0f, 0.70710678118654752f, 0.0f, -0.70710678118654752f, -1.0f, -0.70710678118654752f, 0.0f,
+                          0.70710678118654752f};
+    const c32 cs1 = mk(csc[kt & 7], csc[(kt + 6) & 7]);  // cos, sin of pi k / 4
+
+    c32 *body = s_body[wave];
+    const int nseg = 9 + nsym;
+    const float amp = d.scale / 64.0f;
+    const float g12 = amp / sqrtf(24.0f), g52 = amp / sqrtf(104.0f), g56 = amp / sqrtf(112.0f);
+    for (int q = wave; q < nseg; q += TX_WAVES) {
+        int off, len = 80, lead = 48;
+        if (q == 0) { off = 0; len = 160; lead = 32; }
+        else if (q == 1) { off = 160; len = 160; lead = 32; }
+        else off = 320 + 80 * (q - 2);
+        if (q <= 4) {
+            // unsteered legacy part: the same tones on both chains, -200 ns (4 samples) on the second
+            c32 X = mk(0.0f, 0.0f);
+            float gain = g52;
+            if (q == 0) { X = mk(stf, stf); gain = g12; }
+            else if (q == 1) X = mk(ltf_l, 0.0f);
+            else {
+                float v = 0.0f;
+                if (d_l >= 0) {
+                    const int kk = c_tx.deint_l[0][d_l];
+                    const int t = (kk >> 1) + (q == 4 ? 24 : 0);
+                    const unsigned long long str =
+                        q == 2 ? (unsigned long long)s_sig[0] : ((unsigned long long)s_sig[2] << 32) | s_sig[1];
+                    const unsigned win = (unsigned)((str << 6) >> t) & 0x7f;
+                    v = (__popc(win & ((kk & 1) ? 0171u : 0133u)) & 1) ? 1.0f : -1.0f;
+                } else if (pil >= 0) {
+                    v = base_pil[pil];
+                }
+                X = (q == 4 && pil < 0) ? mk(0.0f, v) : mk(v, 0.0f);
+            }
+            const c32 x = wave_idft64(X, lane);
+            emit(x, lane, body, iq0 + d.out_off, off, len, lead, 0, gain, d.cfo_rad, q == 0, false);
+            emit(x, lane, body, iq1 + d.out_off, off, len, lead, 4, gain, d.cfo_rad, q == 0, false);
+            continue;
+        }
+        // steered part: the two streams' tone values
+        c32 X0 = mk(0.0f, 0.0f), X1 = mk(0.0f, 0.0f);
+        float gain = g56;
+        if (q == 5) {
+            X0 = X1 = mk(stf, stf);
+            gain = g12;
+        } else if (q <= 7) {
+            const int il = q - 6;
+            float v0 = ltf_nl * (il == 1 ? -1.0f : 1.0f), v1 = ltf_nl;  // P rows (1 -1), (1 1)
+            if (pil >= 0) v0 = v1 = ltf_nl * (il == 0 ? 1.0f : -1.0f);  // pilots: R row on both streams
+            X0 = mk(v0, 0.0f);
+            X1 = mk(v1, 0.0f);
+        } else if (q == 8) {
+            float v[2] = {0.0f, 0.0f};
+            if (d_nl >= 0) {
+                const int kk = c_tx.deint_nl[0][d_nl];
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    const unsigned win = (unsigned)(((unsigned long long)s_sig[3 + u] << 6) >> (kk >> 1)) & 0x7f;
+                    v[u] = (__popc(win & ((kk & 1) ? 0171u : 0133u)) & 1) ? 1.0f : -1.0f;
+                }
+            } else if (pil >= 0) {
+                v[0] = v[1] = base_pil[pil];
+            }
+            X0 = mk(v[0], 0.0f);
+            X1 = mk(v[1], 0.0f);
+        } else {
+            const int ns = q - 9;
+            c32 X[2] = {mk(0.0f, 0.0f), mk(0.0f, 0.0f)};
+            if (d_nl >= 0) {
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    const int nb = mu[u].nbpscs, t0 = ns * mu[u].ndbps;
+                    int chip = 0;
+#pragma unroll
+                    for (int b = 0; b < 8; b++)
+                        if (b < nb) chip |= coded_bit(s_bits[u], t0 + tpos[u][b], (gsel[u] >> b) & 1) << b;
+                    if (nb == 1) X[u] = mk(chip ? 1.0f : -1.0f, 0.0f);
+                    else X[u] = mk(gray_level(chip & ((1 << (nb >> 1)) - 1), nb >> 1) * qnorm[u],
+                                   gray_level(chip >> (nb >> 1), nb >> 1) * qnorm[u]);
+                }
+            } else if (pil >= 0) {
+                const float pv = base_pil[(pil + ns) & 3] * c_tx.pilot_p[(4 + ns) % 127];
+                X[0] = X[1] = mk(pv, 0.0f);
+            }
+            X0 = X[0];
+            X1 = X[1];
+        }
+        X1 = cmul(X1, cs1);
+        const c32 Y0 = cadd(cmul(q00, X0), cmul(q01, X1)), Y1 = cadd(cmul(q10, X0), cmul(q11, X1));
+        const c32 y0 = wave_idft64(Y0, lane);
+        emit(y0, lane, body, iq0 + d.out_off, off, len, lead, 0, gain, d.cfo_rad, false, q == nseg - 1);
+        const c32 y1 = wave_idft64(Y1, lane);
+        emit(y1, lane, body, iq1 + d.out_off, off, len, lead, 0, gain, d.cfo_rad, false, q == nseg - 1);
+    }
+}
+
+void launch_tx_mu(const uint8_t *psdu, uint64_t psdu_bytes, const gr80211_tx_mu_desc *desc, int n, const void *qmat, int n_q,
+                  void *iq0, void *iq1, uint64_t arena_len, int32_t *n_samples, hipStream_t s)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_tx_mu, dim3(n), dim3(64 * TX_WAVES), 0, s, psdu, (unsigned long long)psdu_bytes, desc, n,
+                       (const c32 *)qmat, n_q, (c32 *)iq0, (c32 *)iq1, (unsigned long long)arena_len, n_samples);
 }
 
 }  // namespace gr80211

@@ -53,6 +53,10 @@ DEC_DESC_DTYPE = np.dtype([("llr_off", "<i8"), ("n_llr", "<i4"), ("format", "<i4
 TX_DESC_DTYPE = np.dtype([("out_off", "<u8"), ("psdu_off", "<u4"), ("psdu_len", "<i4"), ("format", "<i4"),
                           ("mcs", "<i4"), ("nss", "<i4"), ("scrambler", "<i4"), ("scale", "<f4"), ("cfo_rad", "<f4")])
 assert TX_DESC_DTYPE.itemsize == 40
+TX_MU_DESC_DTYPE = np.dtype([("out_off", "<u8"), ("psdu_off", "<u4", (2,)), ("psdu_len", "<i4", (2,)), ("mcs", "<i4", (2,)),
+                             ("group_id", "<i4"), ("q_index", "<i4"), ("scrambler", "<i4"), ("scale", "<f4"),
+                             ("cfo_rad", "<f4"), ("reserved", "<u4")])
+assert TX_MU_DESC_DTYPE.itemsize == 56
 assert FRAME_DESC_DTYPE.itemsize == C.sizeof(FrameDesc) == 32
 assert FRAME_INFO_DTYPE.itemsize == C.sizeof(FrameInfo) == 112
 assert DEC_DESC_DTYPE.itemsize == C.sizeof(DecDesc) == 40
@@ -61,7 +65,7 @@ EXPORTS = [
     "gr80211_create", "gr80211_destroy", "gr80211_last_error", "gr80211_sync", "gr80211_rx_batch", "gr80211_signal_batch", "gr80211_detect", "gr80211_rx_capture",
     "gr80211_demod_batch", "gr80211_decode_batch", "gr80211_dev_alloc", "gr80211_dev_free",
     "gr80211_copy_h2d", "gr80211_copy_d2h", "gr80211_set_profiling", "gr80211_last_timing",
-    "gr80211_version", "gr80211_table_checksum", "gr80211_tx_samples", "gr80211_tx_batch", "gr80211_set_mu_pos", "gr80211_set_ampdu_strict",
+    "gr80211_version", "gr80211_table_checksum", "gr80211_tx_samples", "gr80211_tx_batch", "gr80211_set_mu_pos", "gr80211_set_ampdu_strict", "gr80211_tx_mu_batch",
 ]
 
 _lib = None
@@ -102,6 +106,7 @@ def load_library():
     L.gr80211_last_timing.argtypes = [vp, C.POINTER(C.c_float), C.c_int]
     L.gr80211_tx_samples.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
     L.gr80211_tx_batch.argtypes = [vp, vp, C.c_uint64, vp, C.c_int, C.c_uint, vp, vp, C.c_uint64, vp, vp]
+    L.gr80211_tx_mu_batch.argtypes = [vp, vp, C.c_uint64, vp, C.c_int, C.c_uint, vp, C.c_int, vp, vp, C.c_uint64, vp, vp]
     L.gr80211_version.restype = C.c_char_p
     L.gr80211_table_checksum.restype = C.c_uint32
     _lib = L
@@ -350,6 +355,21 @@ class RxContext:
             C.c_void_p(iq1.data_ptr()) if iq1 is not None else None, iq0.numel(), C.c_void_p(ns.data_ptr()),
             self._stream())
         self._check(rc, "gr80211_tx_batch")
+        return ns[:n_frames]
+
+    def tx_mu_batch(self, psdu, desc, n_frames, q, iq0, iq1):
+        """Two-user MU-MIMO frames.  q: complex64 CUDA tensor [n_q, 64, 2, 2] (FFT bin, chain, stream)."""
+        t = self.torch
+        assert psdu.is_cuda and psdu.dtype == t.uint8 and psdu.is_contiguous()
+        assert q.is_cuda and q.dtype == t.complex64 and q.is_contiguous() and tuple(q.shape[1:]) == (64, 2, 2)
+        for a in (iq0, iq1):
+            assert a.is_cuda and a.dtype == t.complex64 and a.is_contiguous() and a.numel() == iq0.numel()
+        ns = t.empty(max(n_frames, 1), dtype=t.int32, device=self.dev)
+        dp, flags, keep = self._desc_arg(desc)
+        rc = self.lib.gr80211_tx_mu_batch(
+            self.h, C.c_void_p(psdu.data_ptr()), psdu.numel(), dp, n_frames, flags, C.c_void_p(q.data_ptr()), q.shape[0],
+            C.c_void_p(iq0.data_ptr()), C.c_void_p(iq1.data_ptr()), iq0.numel(), C.c_void_p(ns.data_ptr()), self._stream())
+        self._check(rc, "gr80211_tx_mu_batch")
         return ns[:n_frames]
 
     @staticmethod

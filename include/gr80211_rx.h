@@ -100,6 +100,24 @@ typedef struct {
 #define GR80211_FLAG_DESC_ON_DEVICE 1u /* the descriptor array argument is a device pointer */
 
 /*
+ * One two-user VHT MU-MIMO frame to transmit: the arguments of the reference's Python generator
+ * phy80211.genAmpduMu(nUser=2, bfQ, groupId, ampdu0, mod0, ampdu1, mod1) (tools/phy80211.py:183-224), one
+ * space-time stream per user.
+ */
+typedef struct {
+    uint64_t out_off;     /* sample index in both output arenas where the frame starts */
+    uint32_t psdu_off[2]; /* byte offsets of the users' A-MPDUs in d_psdu */
+    int32_t psdu_len[2];  /* their lengths in bytes: multiples of 4 (as mac80211.genAmpduVHT builds them) */
+    int32_t mcs[2];       /* VHT MCS 0..8 of each user */
+    int32_t group_id;     /* 1..62 */
+    int32_t q_index;      /* which steering matrix set of d_q the frame uses */
+    int32_t scrambler;    /* initial scrambler state 1..127 */
+    float scale;          /* genFinalSig's multiplier */
+    float cfo_rad;        /* rotation per sample */
+    uint32_t reserved;
+} gr80211_tx_mu_desc; /* 56 bytes */
+
+/*
  * One frame to transmit: what the reference's Python generator takes in
  * phy80211.genFromMpdu(mpdu, modulation(format, mcs, bw20, nSTS, shortGi=False)) / genFromAmpdu(ampdu, ...)
  * (tools/phy80211.py:80-181) and genFinalSig(multiplier, cfoHz, ...) (tools/phy80211.py:1077-1094).
@@ -232,6 +250,17 @@ int gr80211_tx_samples(int format, int mcs, int nss, int psdu_len);
 int gr80211_tx_batch(gr80211_ctx *ctx, const uint8_t *d_psdu, uint64_t psdu_bytes, const gr80211_tx_desc *desc,
                      int n_frames, unsigned flags, void *d_iq0, void *d_iq1, uint64_t arena_len,
                      int32_t *d_n_samples, void *stream);
+
+/*
+ * Two-user MU-MIMO transmitter (tools/phy80211.py genAmpduMu 183-224, __genVhtSignalBMu 596-662, __genOfdmSignalMu
+ * 815-838).  d_q: n_q sets of steering matrices, complex64 [set][FFT bin 0..63][transmit chain 0..1][stream 0..1]
+ * (bfQ of the generator, in FFT-bin order); from the VHT-STF on every tone is mapped through its matrix, the legacy
+ * part and VHT-SIG-A are sent unsteered on both chains.  Output and d_n_samples as for gr80211_tx_batch; both arenas
+ * are required.
+ */
+int gr80211_tx_mu_batch(gr80211_ctx *ctx, const uint8_t *d_psdu, uint64_t psdu_bytes, const gr80211_tx_mu_desc *desc,
+                        int n_frames, unsigned flags, const void *d_q, int n_q, void *d_iq0, void *d_iq1,
+                        uint64_t arena_len, int32_t *d_n_samples, void *stream);
 
 /* Device memory helpers so that a C / FFI caller needs no HIP binding of its own. */
 void *gr80211_dev_alloc(gr80211_ctx *ctx, size_t bytes);

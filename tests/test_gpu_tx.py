@@ -180,3 +180,76 @@ def test_closed_loop_unique_frames(pkg, rxctx):
     out, out_len, n_pdu = res["out"].cpu().numpy(), res["out_len"].cpu().numpy(), res["n_pdu"].cpu().numpy()
     bad = [i for i in range(n) if n_pdu[i] != 1 or bytes(out[i, 3:out_len[i] - 1]) != mpdus[i]]
     assert not bad, (len(bad), bad[:10])
+
+
+def mu_q(n_sets=1):
+    """Zero-forcing steering matrices of the fixed 2x2 channel (rows = users), normalised as tools/cmu_ap.py does,
+    the same on every tone."""
+    q = np.linalg.inv(H22)
+    q = q / np.linalg.norm(q) * np.sqrt(2.0)
+    return np.ascontiguousarray(np.broadcast_to(q.astype(np.complex64), (n_sets, 64, 2, 2)))
+
+
+def test_tx_mu_equals_python_reference_waveform(pkg, rxctx):
+    """The two-user MU-MIMO frame of the reference's Python generator (genAmpduMu), reproduced on the GPU: the
+    fixture holds what the two users' antennas receive through the fixed channel."""
+    import torch
+    from util import golden_mu
+    tx = pkg.txgen
+    g = golden_mu()
+    amp = [tx.ampdu_vht([m]) for m in g["mpdus"]]
+    d = np.zeros(1, dtype=pkg.rx.TX_MU_DESC_DTYPE)
+    d[0]["out_off"], d[0]["psdu_off"], d[0]["psdu_len"] = 32, (0, len(amp[0])), (len(amp[0]), len(amp[1]))
+    d[0]["mcs"], d[0]["group_id"], d[0]["scrambler"], d[0]["scale"] = g["mcs"], 2, 93, 18.0
+    n = g["iq"].shape[1] - 800
+    iq0 = torch.zeros(n + 64, dtype=torch.complex64, device="cuda")
+    iq1 = torch.zeros(n + 64, dtype=torch.complex64, device="cuda")
+    psdu = torch.from_numpy(np.frombuffer(amp[0] + amp[1], np.uint8).copy()).cuda()
+    ns = rxctx.tx_mu_batch(psdu, d, 1, torch.from_numpy(mu_q()).cuda(), iq0, iq1)
+    assert int(ns[0]) == n
+    got = np.stack([iq0.cpu().numpy()[32:32 + n], iq1.cpu().numpy()[32:32 + n]]).astype(np.complex128)
+    ref = g["iq"][:, 400:400 + n]
+    assert np.abs(H22 @ got - ref).max() < TOL * 18 * 4
+    assert not iq0.cpu().numpy()[:32].any() and not iq1.cpu().numpy()[32 + n:].any()
+
+
+def test_mu_closed_loop(pkg, rxctx):
+    """300 two-user frames with unique payloads and mixed MCS pairs: transmit on the GPU with the zero-forcing Q,
+    pass the 2x2 channel, add noise, and let each user's one-antenna receiver (with its group position) take its
+    own A-MPDU out."""
+    import torch
+    tx = pkg.txgen
+    rng = np.random.default_rng(83)
+    n = 300
+    d = np.zeros(n, dtype=pkg.rx.TX_MU_DESC_DTYPE)
+    blob, mpdus, pos, sync = bytearray(), [], 64, []
+    for i in range(n):
+        mcs = (int(rng.integers(0, 9)), int(rng.integers(0, 9)))
+        ms = [tx.make_mpdu(int(rng.integers(30, 400)), rng) for _ in range(2)]
+        am = [tx.ampdu_vht([m]) for m in ms]
+        nsym = max(tx.Mod(2, mcs[u], 1).set_len(len(am[u])).nsym for u in range(2))
+        ns = 400 + 160 + 80 + 160 + 80 + 80 * nsym
+        d[i]["out_off"], d[i]["mcs"], d[i]["group_id"], d[i]["scrambler"], d[i]["scale"] = pos, mcs, 1 + i % 62, 1 + i % 127, 18.0
+        d[i]["psdu_off"], d[i]["psdu_len"] = (len(blob), len(blob) + len(am[0])), (len(am[0]), len(am[1]))
+        blob += am[0] + am[1]
+        mpdus.append(ms)
+        sync.append(pos + 176)
+        pos += ns + 100
+    t0 = torch.zeros(pos, dtype=torch.complex64, device="cuda")
+    t1 = torch.zeros(pos, dtype=torch.complex64, device="cuda")
+    psdu = torch.from_numpy(np.frombuffer(bytes(blob), np.uint8).copy()).cuda()
+    ns = rxctx.tx_mu_batch(psdu, d, n, torch.from_numpy(mu_q()).cuda(), t0, t1).cpu().numpy()
+    assert (ns > 0).all()
+    h = torch.tensor(H22, dtype=torch.complex64, device="cuda")
+    sigma = 18.0 / 64.0 * 10 ** (-38.0 / 20) / np.sqrt(2.0)
+    g = torch.Generator(device="cuda").manual_seed(6)
+    navail = (ns - 176 + 60).astype(np.uint32)
+    for u in range(2):
+        r = h[u, 0] * t0 + h[u, 1] * t1
+        r = (r + sigma * torch.view_as_complex(torch.randn((pos, 2), generator=g, device="cuda"))).contiguous()
+        desc = rxctx.make_desc(np.array(sync, np.uint64), navail, mu_pos=np.full(n, u, np.uint32))
+        res = rxctx.rx_batch(r, None, desc, n, out_stride=512)
+        rxctx.sync()
+        out, out_len, n_pdu = res["out"].cpu().numpy(), res["out_len"].cpu().numpy(), res["n_pdu"].cpu().numpy()
+        bad = [i for i in range(n) if n_pdu[i] != 1 or bytes(out[i, 3:out_len[i] - 1]) != mpdus[i][u]]
+        assert not bad, (u, len(bad), bad[:10])
