@@ -256,7 +256,8 @@ int gr80211_tx_batch(gr80211_ctx *ctx, const uint8_t *d_psdu, uint64_t psdu_byte
  * 815-838).  d_q: n_q sets of steering matrices, complex64 [set][FFT bin 0..63][transmit chain 0..1][stream 0..1]
  * (bfQ of the generator, in FFT-bin order); from the VHT-STF on every tone is mapped through its matrix, the legacy
  * part and VHT-SIG-A are sent unsteered on both chains.  Output and d_n_samples as for gr80211_tx_batch; both arenas
- * are required.
+ * are required.  Both users are padded to the longer one's symbol count; a frame whose padded PSDU would exceed
+ * 4098 bytes for either user (very unequal rates) is rejected.
  */
 int gr80211_tx_mu_batch(gr80211_ctx *ctx, const uint8_t *d_psdu, uint64_t psdu_bytes, const gr80211_tx_mu_desc *desc,
                         int n_frames, unsigned flags, const void *d_q, int n_q, void *d_iq0, void *d_iq1,

@@ -213,7 +213,7 @@ def test_tx_mu_equals_python_reference_waveform(pkg, rxctx):
     assert not iq0.cpu().numpy()[:32].any() and not iq1.cpu().numpy()[32 + n:].any()
 
 
-def test_mu_closed_loop(pkg, rxctx):
+def test_mu_closed_loop(pkg, rxctx, oracle):
     """300 two-user frames with unique payloads and mixed MCS pairs: transmit on the GPU with the zero-forcing Q,
     pass the 2x2 channel, add noise, and let each user's one-antenna receiver (with its group position) take its
     own A-MPDU out."""
@@ -224,10 +224,15 @@ def test_mu_closed_loop(pkg, rxctx):
     d = np.zeros(n, dtype=pkg.rx.TX_MU_DESC_DTYPE)
     blob, mpdus, pos, sync = bytearray(), [], 64, []
     for i in range(n):
-        mcs = (int(rng.integers(0, 9)), int(rng.integers(0, 9)))
-        ms = [tx.make_mpdu(int(rng.integers(30, 400)), rng) for _ in range(2)]
-        am = [tx.ampdu_vht([m]) for m in ms]
-        nsym = max(tx.Mod(2, mcs[u], 1).set_len(len(am[u])).nsym for u in range(2))
+        while True:
+            mcs = (int(rng.integers(0, 9)), int(rng.integers(0, 9)))
+            ms = [tx.make_mpdu(int(rng.integers(30, 400)), rng) for _ in range(2)]
+            am = [tx.ampdu_vht([m]) for m in ms]
+            mods = [tx.Mod(2, mcs[u], 1).set_len(len(am[u])) for u in range(2)]
+            nsym = max(m.nsym for m in mods)
+            # both users are padded to the longer one's symbol count; the padded PSDU is limited to 4098 bytes
+            if all((nsym * m.ndbps - 22) // 8 <= 4098 for m in mods):
+                break
         ns = 400 + 160 + 80 + 160 + 80 + 80 * nsym
         d[i]["out_off"], d[i]["mcs"], d[i]["group_id"], d[i]["scrambler"], d[i]["scale"] = pos, mcs, 1 + i % 62, 1 + i % 127, 18.0
         d[i]["psdu_off"], d[i]["psdu_len"] = (len(blob), len(blob) + len(am[0])), (len(am[0]), len(am[1]))
@@ -252,4 +257,11 @@ def test_mu_closed_loop(pkg, rxctx):
         rxctx.sync()
         out, out_len, n_pdu = res["out"].cpu().numpy(), res["out_len"].cpu().numpy(), res["n_pdu"].cpu().numpy()
         bad = [i for i in range(n) if n_pdu[i] != 1 or bytes(out[i, 3:out_len[i] - 1]) != mpdus[i][u]]
-        assert not bad, (u, len(bad), bad[:10])
+        # A user whose own data ends well before the common last symbol is decoded by the reference rule over its own
+        # symbol count only, i.e. without tail bits at the end of its trellis: when its MPDU ends within a few bits
+        # of that point the last bits can come out wrong.  Such frames must fail in the oracle in the same way.
+        assert len(bad) <= n // 20, (u, len(bad))
+        host = r.cpu().numpy()
+        for i in bad:
+            ref = oracle.rx_frame(host[: int(sync[i]) + int(navail[i])], None, int(sync[i]), 0.0, want_llr=False, mu_pos=u)
+            assert bytes(out[i, : out_len[i]]) == ref["blob"] and int(n_pdu[i]) == ref["n_pdu"], (u, i)
