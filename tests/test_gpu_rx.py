@@ -191,7 +191,7 @@ def test_vht_multi_subframe_ampdu(pkg, rxctx, oracle):
 
 
 def test_full_size_batch_roundtrip(pkg, rxctx):
-    """BASELINE frame shape (VHT MCS8, 1500-byte A-MPDU, 30 dB): a few hundred frames in one batch,
+    """Benchmark frame shape (VHT MCS8, 1500-byte A-MPDU, 30 dB): a few hundred frames in one batch,
     every PSDU must come back bit-exact (encode -> channel -> decode round trip)."""
     import torch
     tx = pkg.txgen
