@@ -1,0 +1,139 @@
+// Streaming C-ABI over the host blocks (include/gr80211_host.h).
+#include <memory>
+#include <string>
+
+#include "../../include/gr80211_host.h"
+#include "gr80211_blocks.h"
+
+using namespace gr80211::host;
+
+struct gr80211_block {
+    std::shared_ptr<block> b;
+    int kind = 0;
+    int n_in = 1;
+    gr80211_msg_fn fn = nullptr;
+    void *user = nullptr;
+    std::string err;
+};
+
+namespace {
+
+thread_local std::string g_create_err = "null block";
+
+const char *const kTagNames[] = {"rad", "snr", "rssi", "format", "len", "total", "cr", "mcs", "ampdu", "trellis", "mu2x1chan"};
+
+}  // namespace
+
+extern "C" {
+
+gr80211_block *gr80211_block_create(int kind, int batch_frames, int device)
+{
+    std::unique_ptr<gr80211_block> h(new gr80211_block());
+    h->kind = kind;
+    const int batch = batch_frames > 0 ? batch_frames : 4096;
+    switch (kind) {
+    case GR80211_BLOCK_DECODE: h->b = decode::make(false, batch, device); h->n_in = 1; break;
+    case GR80211_BLOCK_RX: h->b = rx::make(1, batch, device); h->n_in = 2; break;
+    case GR80211_BLOCK_RX2: h->b = rx::make(2, batch, device); h->n_in = 3; break;
+    case GR80211_BLOCK_CAPTURE: h->b = capture_rx::make(1, device); h->n_in = 1; break;
+    case GR80211_BLOCK_CAPTURE2: h->b = capture_rx::make(2, device); h->n_in = 2; break;
+    default: g_create_err = "gr80211_block_create: unknown block kind"; return nullptr;
+    }
+    if (!h->b || !h->b->last_error().empty()) {
+        g_create_err = h->b ? h->b->last_error() : std::string("gr80211_block_create: no block");
+        return nullptr;
+    }
+    gr80211_block *raw = h.release();
+    raw->b->set_msg_handler([raw](const std::string &, const pdu_t &m) {
+        if (raw->fn) raw->fn(raw->user, m.blob.data(), (int)m.blob.size());
+    });
+    return raw;
+}
+
+void gr80211_block_destroy(gr80211_block *b) { delete b; }
+
+void gr80211_block_set_msg_handler(gr80211_block *b, gr80211_msg_fn fn, void *user)
+{
+    if (!b) return;
+    b->fn = fn;
+    b->user = user;
+}
+
+int gr80211_block_set_option(gr80211_block *b, int option, int value)
+{
+    if (!b) return -1;
+    decode *d = dynamic_cast<decode *>(b->b.get());
+    rx *r = dynamic_cast<rx *>(b->b.get());
+    capture_rx *c = dynamic_cast<capture_rx *>(b->b.get());
+    if (option == GR80211_OPT_MU_POS) {
+        if (value < 0 || value > 1 || d) return -1;
+        if (r) r->set_mu_pos(value);
+        if (c) c->set_mu_pos(value);
+        return 0;
+    }
+    if (option == GR80211_OPT_AMPDU_STRICT) {
+        if (d) d->set_ampdu_strict(value != 0);
+        if (r) r->set_ampdu_strict(value != 0);
+        if (c) c->set_ampdu_strict(value != 0);
+        return 0;
+    }
+    return -1;
+}
+
+int gr80211_block_n_inputs(const gr80211_block *b) { return b ? b->n_in : -1; }
+
+int gr80211_block_forecast(gr80211_block *b, int noutput_items, int *ninput_items_required, int n_inputs)
+{
+    if (!b || !ninput_items_required || n_inputs != b->n_in) return -1;
+    gr_vector_int req((size_t)n_inputs, 0);
+    b->b->forecast(noutput_items, req);
+    for (int i = 0; i < n_inputs; i++) ninput_items_required[i] = req[(size_t)i];
+    return 0;
+}
+
+int gr80211_block_work(gr80211_block *b, int noutput_items, const int *ninput_items, const void *const *input_items,
+                       int n_inputs, const gr80211_tag *tags, int n_tags, int *consumed)
+{
+    if (!b || !ninput_items || !input_items || n_inputs != b->n_in || n_tags < 0 || (n_tags > 0 && !tags)) return -1;
+    // the caller hands over every tag of the offered windows with each call, so nothing is kept between calls
+    b->b->clear_item_tags_in();
+    for (int i = 0; i < n_tags; i++) {
+        const gr80211_tag &t = tags[i];
+        if (t.port >= (uint32_t)n_inputs || t.key > GR80211_TAG_MU2X1CHAN) {
+            b->err = "gr80211_block_work: bad tag";
+            return -1;
+        }
+        tag_t h;
+        h.offset = t.offset;
+        h.key = kTagNames[t.key];
+        h.value = t.value;
+        if (t.cvec && t.cvec_len)
+            for (uint32_t k = 0; k < t.cvec_len; k++) h.cvec.emplace_back(t.cvec[2 * k], t.cvec[2 * k + 1]);
+        b->b->add_item_tag_in((int)t.port, h);
+    }
+    gr_vector_int nin(ninput_items, ninput_items + n_inputs);
+    gr_vector_const_void_star in(input_items, input_items + n_inputs);
+    gr_vector_void_star out;
+    const int produced = b->b->general_work(noutput_items, nin, in, out);
+    if (consumed) *consumed = b->b->consumed();
+    b->b->commit();
+    if (!b->b->last_error().empty()) {
+        b->err = b->b->last_error();
+        return -2;
+    }
+    return produced;
+}
+
+int gr80211_block_flush(gr80211_block *b)
+{
+    if (!b) return -1;
+    if (!b->b->flush()) {
+        b->err = b->b->last_error();
+        return -2;
+    }
+    return 0;
+}
+
+const char *gr80211_block_last_error(const gr80211_block *b) { return b ? b->err.c_str() : g_create_err.c_str(); }
+
+}  // extern "C"

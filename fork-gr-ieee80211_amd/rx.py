@@ -78,6 +78,9 @@ def load_library():
         return _lib
     if not os.path.exists(LIB_PATH):
         raise RuntimeError("HIP library %s not built; run __graft_entry__.build()" % LIB_PATH)
+    # torch ships a HIP runtime of its own: it has to be the one already loaded when the library's libamdhip64
+    # dependency is resolved, or a process that uses both ends up with two runtimes and torch sees no device
+    import torch  # noqa: F401
     L = C.CDLL(LIB_PATH)
     vp = C.c_void_p
     L.gr80211_create.argtypes = [C.POINTER(vp), C.c_int]

@@ -1,0 +1,86 @@
+/*
+ * Streaming C-ABI of the host blocks (libgr80211_host.so): one entry that mirrors gr::block::general_work, with
+ * stream tags as plain records and published messages through a callback, so that a GNU Radio block wrapper (or
+ * any FFI caller) only translates pmt <-> these records.  Block kinds and what they stand for:
+ *
+ *   GR80211_BLOCK_DECODE    ieee80211::decode (include/gnuradio/ieee80211/decode.h:22-36, lib/decode_impl.cc:60-162):
+ *                           in {float soft bits}; tags format, len, total, cr, mcs, ampdu, trellis (and mu2x1chan)
+ *                           on a packet's first item (lib/decode_impl.cc:70-90)
+ *   GR80211_BLOCK_RX        ieee80211::signal -> demod -> decode as one block: in {u8 sync, c64 samples}
+ *                           (lib/signal_impl.cc:35-37); tags rad, snr, rssi on a set sync byte (lib/signal_impl.cc:83-92)
+ *   GR80211_BLOCK_RX2       ieee80211::signal2 -> demod2 -> decode: in {u8 sync, c64, c64} (lib/signal2_impl.cc:35-37)
+ *   GR80211_BLOCK_CAPTURE   presiso -> trigger -> sync -> signal -> demod -> decode (examples/rx.grc): in {c64}
+ *   GR80211_BLOCK_CAPTURE2  the same with two antennas (examples/rx2.grc): in {c64, c64}
+ *
+ * Every kind has no stream output; messages of port "out" are the blobs `decode` publishes
+ * (lib/decode_impl.cc:512-516).  A block is driven by one thread at a time, like a GNU Radio block.
+ */
+#ifndef GR80211_HOST_H
+#define GR80211_HOST_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GR80211_BLOCK_DECODE 0
+#define GR80211_BLOCK_RX 1
+#define GR80211_BLOCK_RX2 2
+#define GR80211_BLOCK_CAPTURE 3
+#define GR80211_BLOCK_CAPTURE2 4
+
+/* tag keys (the pmt symbols of the reference's tags) */
+#define GR80211_TAG_RAD 0
+#define GR80211_TAG_SNR 1
+#define GR80211_TAG_RSSI 2
+#define GR80211_TAG_FORMAT 3
+#define GR80211_TAG_LEN 4
+#define GR80211_TAG_TOTAL 5
+#define GR80211_TAG_CR 6
+#define GR80211_TAG_MCS 7
+#define GR80211_TAG_AMPDU 8
+#define GR80211_TAG_TRELLIS 9
+#define GR80211_TAG_MU2X1CHAN 10 /* c32vector of 128: cvec points at 256 floats, re/im interleaved */
+
+typedef struct {
+    uint64_t offset; /* absolute item index on the port, like gr::tag_t::offset */
+    uint32_t port;   /* input port the tag sits on */
+    uint32_t key;    /* GR80211_TAG_* */
+    double value;    /* pmt long / float value */
+    const float *cvec; /* vector value (GR80211_TAG_MU2X1CHAN) or NULL */
+    uint32_t cvec_len; /* complex elements in cvec */
+    uint32_t reserved;
+} gr80211_tag;
+
+#define GR80211_OPT_MU_POS 0       /* ieee80211::demod::make(mupos, mugid): position in VHT MU groups, 0 or 1 */
+#define GR80211_OPT_AMPDU_STRICT 1 /* 1: the standard's A-MPDU de-aggregation instead of the reference's */
+
+typedef struct gr80211_block gr80211_block;
+typedef void (*gr80211_msg_fn)(void *user, const uint8_t *blob, int len);
+
+/* batch_frames: frames (packets) collected before the GPU is called; <= 0 selects the default. */
+gr80211_block *gr80211_block_create(int kind, int batch_frames, int device);
+void gr80211_block_destroy(gr80211_block *b);
+void gr80211_block_set_msg_handler(gr80211_block *b, gr80211_msg_fn fn, void *user);
+int gr80211_block_set_option(gr80211_block *b, int option, int value);
+int gr80211_block_n_inputs(const gr80211_block *b);
+/* gr::block::forecast: items needed on every input for noutput_items of progress. */
+int gr80211_block_forecast(gr80211_block *b, int noutput_items, int *ninput_items_required, int n_inputs);
+/*
+ * gr::block::general_work.  ninput_items / input_items: one entry per input port; tags: the tags inside the
+ * offered windows (non-decreasing offsets per port; all of them with every call, as get_tags_in_range over the
+ * window returns them: the block keeps no tag between calls).  *consumed receives what consume_each() was called with.
+ * Returns the items produced (always 0: there is no stream output) or a negative value on error.
+ */
+int gr80211_block_work(gr80211_block *b, int noutput_items, const int *ninput_items, const void *const *input_items,
+                       int n_inputs, const gr80211_tag *tags, int n_tags, int *consumed);
+/* End of stream: decode what is buffered.  0 on success. */
+int gr80211_block_flush(gr80211_block *b);
+/* Text of the block's last error; with b == NULL, why the calling thread's last gr80211_block_create returned NULL. */
+const char *gr80211_block_last_error(const gr80211_block *b);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GR80211_HOST_H */

@@ -6,8 +6,8 @@ import re
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_functions():
-    txt = open(os.path.join(ROOT, "include", "gr80211_rx.h")).read()
+def declared_functions(header="gr80211_rx.h"):
+    txt = open(os.path.join(ROOT, "include", header)).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     return sorted(set(re.findall(r"\b(gr80211_[a-z0-9_]+)\s*\(", txt)))
 
@@ -50,6 +50,22 @@ def test_host_blocks_library_loads():
     ctypes.CDLL(os.path.join(d, "libgr80211_host.so"))
     p = subprocess.run([os.path.join(d, "gr80211_pump")], capture_output=True, text=True, timeout=60)
     assert p.returncode == 2 and "usage" in p.stderr
+
+
+def test_streaming_abi_symbols_exported(pkg):
+    """Every function include/gr80211_host.h declares is exported by libgr80211_host.so; an unknown block kind is
+    refused with a reason (no device is touched for it)."""
+    from importlib import import_module
+    stream = import_module("fork-gr-ieee80211_amd.stream")
+    names = [n for n in declared_functions("gr80211_host.h") if n.startswith("gr80211_block_")]
+    assert sorted(stream.EXPORTS) == names
+    lib = stream.load_host_library()
+    for n in names:
+        assert hasattr(lib, n), n
+    assert ctypes.sizeof(stream.Tag) == 40
+    assert not lib.gr80211_block_create(99, 0, 0)
+    assert b"unknown block kind" in lib.gr80211_block_last_error(None)
+    assert lib.gr80211_block_n_inputs(None) == -1 and lib.gr80211_block_flush(None) == -1
 
 
 def test_tx_frame_lengths_match_generator(pkg):

@@ -186,3 +186,111 @@ def test_rx_block_publishes_ndp_channel(tmp_path, oracle):
     tf, files = write_stream(tmp_path, iq0, None, triggers)
     got, stat = run_pump(["rx", 1, 1500, 8, tf] + files)
     assert got == want
+
+
+# ---- the same blocks through the streaming C-ABI (include/gr80211_host.h), driven from ctypes
+
+
+def sync_stream(n, triggers):
+    sync = np.zeros(n, np.uint8)
+    tags = []
+    for pos, rad in triggers:
+        sync[pos] = 1
+        tags += [(pos, 0, "rad", rad), (pos, 0, "snr", 30.0), (pos, 0, "rssi", -40.0)]
+    return sync, tags
+
+
+@pytest.mark.parametrize("chunk,batch", [(4096, 1000), (777, 2)])
+def test_streaming_abi_rx_block(pkg, oracle, chunk, batch):
+    from importlib import import_module
+    stream = import_module("fork-gr-ieee80211_amd.stream")
+    iq0, triggers, frames = siso_stream(0.002, 6)
+    want, n_frames = model_chain(oracle, iq0, None, triggers)
+    sync, tags = sync_stream(len(iq0), triggers)
+    with stream.StreamBlock(stream.RX, batch) as b:
+        assert b.n_in == 2 and len(b.forecast(512)) == 2
+        got = b.run([sync, iq0], tags, chunk)
+    assert got == want
+    assert [p[3:-1] for p in got] == [f["mpdu"] for f in frames]
+
+
+def test_streaming_abi_rx2_and_capture_blocks(pkg, oracle):
+    from importlib import import_module
+    stream = import_module("fork-gr-ieee80211_amd.stream")
+    rng = np.random.default_rng(9)
+    parts, triggers, pos = [], [], 0
+    for f in [f for f in golden_frames() if f["nss"] == 2]:
+        r = (H22 @ f["iq"]).astype(np.complex64)
+        parts.append(r)
+        triggers.append((pos + f["sync_idx"], f["rad"]))
+        pos += r.shape[1]
+    iq = np.concatenate(parts, axis=1)
+    iq = (iq + 0.001 * (rng.standard_normal(iq.shape) + 1j * rng.standard_normal(iq.shape))).astype(np.complex64)
+    want, n_frames = model_chain(oracle, iq[0], iq[1], triggers)
+    sync, tags = sync_stream(iq.shape[1], triggers)
+    with stream.StreamBlock(stream.RX2, 3) as b:
+        assert b.run([sync, iq[0], iq[1]], tags, 3000) == want
+    iq0, triggers, frames = siso_stream(0.003, 6)
+    det = oracle.detect(iq0)
+    want, _ = model_chain(oracle, iq0, None, list(zip(det["pos"].tolist(), det["rad"].tolist())))
+    with stream.StreamBlock(stream.CAPTURE) as b:
+        assert b.run([iq0], (), 5000) == want
+
+
+def test_streaming_abi_mu_option_and_errors(pkg, oracle):
+    """GR80211_OPT_MU_POS reaches the demodulator: the second user's PSDU of the two-user fixture comes out; bad
+    arguments are refused without touching the device."""
+    from importlib import import_module
+    from util import golden_mu
+    stream = import_module("fork-gr-ieee80211_amd.stream")
+    g = golden_mu()
+    for pos in (0, 1):
+        iq0 = np.concatenate([np.asarray(g["iq"][pos], np.complex64), np.zeros(300, np.complex64)])
+        ref = oracle.rx_frame(iq0, None, int(g["sync_idx"]), 0.0, want_llr=False, mu_pos=pos)
+        sync, tags = sync_stream(len(iq0), [(int(g["sync_idx"]), 0.0)])
+        with stream.StreamBlock(stream.RX, 4) as b:
+            b.set_option(stream.OPT_MU_POS, pos)
+            got = b.run([sync, iq0], tags, 2048)
+        assert got == [blob_of(p) for p in ref["pdus"]] and [p[3:-1] for p in got] == [g["mpdus"][pos]]
+    with stream.StreamBlock(stream.DECODE, 4) as b:
+        with pytest.raises(RuntimeError):
+            b.set_option(stream.OPT_MU_POS, 1)
+        with pytest.raises(RuntimeError):
+            b.work([np.zeros(8, np.float32)], [(0, 3, "format", 0)])
+    with pytest.raises(RuntimeError):
+        stream.StreamBlock(17)
+
+
+def test_streaming_abi_decode_block(pkg, rxctx, oracle):
+    """decode through the streaming C-ABI: the tags of a packet's first soft bit as records, a sounding packet
+    (trellis 0) whose channel vector travels in the tag, and the oracle's PSDUs for the rest."""
+    import torch
+    from importlib import import_module
+    from util import build_arena
+    stream = import_module("fork-gr-ieee80211_amd.stream")
+    frames = [f for f in golden_frames() if f["nss"] == 1]
+    iq0, iq1, sync, navail = build_arena([([f["iq"][0]], f["sync_idx"]) for f in frames])
+    rads = np.array([f["rad"] for f in frames], np.float32)
+    info, llr = rxctx.demod_batch(torch.from_numpy(iq0).cuda(), None, rxctx.make_desc(sync, navail, rad=rads), len(frames))
+    chan = (np.arange(128) * (0.5 - 0.25j)).astype(np.complex64)
+    parts, tags, want, at = [], [], [], 0
+    for i, f in enumerate(frames):
+        tot, o = int(info["total"][i]), int(info["llr_off"][i])
+        for key in ("format", "len", "total", "cr", "mcs", "ampdu", "trellis"):
+            tags.append((at, 0, key, int(info[key][i])))
+        parts.append(llr[o:o + tot])
+        at += tot
+        ref = oracle.rx_frame(iq0[: int(sync[i]) + int(navail[i])], None, int(sync[i]), float(rads[i]), want_llr=False)
+        want += [blob_of(p) for p in ref["pdus"]]
+        if i == 1:
+            for key, v in (("format", 2), ("len", 0), ("total", 16), ("cr", 0), ("mcs", 0), ("ampdu", 0), ("trellis", 0)):
+                tags.append((at, 0, key, v))
+            tags.append((at, 0, "mu2x1chan", 0, chan))
+            parts.append(np.zeros(16, np.float32))
+            at += 16
+            want.append(bytes([20, 0, 4]) + chan.tobytes())
+    parts.append(np.zeros(200, np.float32))
+    with stream.StreamBlock(stream.DECODE, 2) as b:
+        assert b.forecast(1000) == [1160]
+        got = b.run([np.concatenate(parts).astype(np.float32)], tags, 1500)
+    assert got == want
