@@ -572,6 +572,7 @@ void gr80211_dev_free(gr80211_ctx *c, void *p)
 int gr80211_copy_h2d(gr80211_ctx *c, void *d_dst, const void *h_src, size_t bytes, void *stream)
 {
     if (!c) return GR80211_ERR_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t s = pick(c, stream);
     HIP_TRY(c, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, s));
     HIP_TRY(c, hipStreamSynchronize(s));
@@ -581,6 +582,7 @@ int gr80211_copy_h2d(gr80211_ctx *c, void *d_dst, const void *h_src, size_t byte
 int gr80211_copy_d2h(gr80211_ctx *c, void *h_dst, const void *d_src, size_t bytes, void *stream)
 {
     if (!c) return GR80211_ERR_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t s = pick(c, stream);
     HIP_TRY(c, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
