@@ -569,6 +569,20 @@ void gr80211_dev_free(gr80211_ctx *c, void *p)
     if (c && p) (void)hipFree(p);
 }
 
+void *gr80211_host_alloc(gr80211_ctx *c, size_t bytes)
+{
+    if (!c) return nullptr;
+    if (hipSetDevice(c->device) != hipSuccess) return nullptr;
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1) != hipSuccess) return nullptr;
+    return p;
+}
+
+void gr80211_host_free(gr80211_ctx *c, void *p)
+{
+    if (c && p) (void)hipHostFree(p);
+}
+
 int gr80211_copy_h2d(gr80211_ctx *c, void *d_dst, const void *h_src, size_t bytes, void *stream)
 {
     if (!c) return GR80211_ERR_ARG;
@@ -585,6 +599,16 @@ int gr80211_copy_d2h(gr80211_ctx *c, void *h_dst, const void *d_src, size_t byte
     HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t s = pick(c, stream);
     HIP_TRY(c, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    return GR80211_OK;
+}
+
+int gr80211_copy_d2d(gr80211_ctx *c, void *d_dst, const void *d_src, size_t bytes, void *stream)
+{
+    if (!c) return GR80211_ERR_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = pick(c, stream);
+    HIP_TRY(c, hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, s));
     HIP_TRY(c, hipStreamSynchronize(s));
     return GR80211_OK;
 }

@@ -33,31 +33,75 @@ const tag_t *tag_find(const std::vector<tag_t> &tags, const char *key)
     return r;
 }
 
+// Index of the first non-zero byte of s[i, n), or n: a sync stream is almost all zeros, so eight bytes go at a time.
+int next_set(const uint8_t *s, int i, int n)
+{
+    while (i + 8 <= n) {
+        uint64_t w;
+        memcpy(&w, s + i, 8);
+        if (w) break;
+        i += 8;
+    }
+    while (i < n && !s[i]) i++;
+    return i;
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------ block
 block::block(int n_in) : d_read(n_in, 0), d_tags(n_in) {}
 block::~block() {}
 
-void block::add_item_tag_in(int port, const tag_t &t) { d_tags[port].push_back(t); }
+void block::add_item_tag_in(int port, const tag_t &t)
+{
+    // kept sorted by offset (tags of one offset in arrival order); the usual case appends
+    std::deque<tag_t> &tv = d_tags[port];
+    if (tv.empty() || tv.back().offset <= t.offset) {
+        tv.push_back(t);
+        return;
+    }
+    auto it = std::upper_bound(tv.begin(), tv.end(), t.offset, [](uint64_t o, const tag_t &x) { return o < x.offset; });
+    tv.insert(it, t);
+}
 
 void block::get_tags_in_range(std::vector<tag_t> &v, int port, uint64_t start, uint64_t end) const
 {
     v.clear();
-    for (const tag_t &t : d_tags[port])
-        if (t.offset >= start && t.offset < end) v.push_back(t);
+    const std::deque<tag_t> &tv = d_tags[port];
+    auto it = std::lower_bound(tv.begin(), tv.end(), start, [](const tag_t &t, uint64_t o) { return t.offset < o; });
+    for (; it != tv.end() && it->offset < end; ++it) v.push_back(*it);
 }
 
 void block::commit()
 {
     for (size_t p = 0; p < d_read.size(); p++) {
         d_read[p] += (uint64_t)d_consumed;
-        std::vector<tag_t> &tv = d_tags[p];
-        size_t k = 0;
-        while (k < tv.size() && tv[k].offset < d_read[p]) k++;
-        if (k) tv.erase(tv.begin(), tv.begin() + k);
+        std::deque<tag_t> &tv = d_tags[p];
+        while (!tv.empty() && tv.front().offset < d_read[p]) tv.pop_front();
     }
     d_consumed = 0;
+}
+
+uint64_t block::publish_slots(const uint8_t *out, const int32_t *len, int n, int stride)
+{
+    uint64_t n_pub = 0;
+    for (int i = 0; i < n; i++) {
+        // a slot holds the frame's messages back to back: [format][len lo][len hi][MPDU][mcs]
+        const uint8_t *p = out + (size_t)i * (size_t)stride;
+        int at = 0;
+        while (at + 4 <= len[i]) {
+            const int L = p[at + 1] | (p[at + 2] << 8);
+            const int rec = L + (p[at] == F_VHT_CHAN ? 3 : 4);  // a channel message has no trailing mcs byte
+            if (at + rec > len[i] || at + rec > stride) break;
+            pdu_t m;
+            m.blob.assign(p + at, p + at + rec);
+            m.len = rec;
+            message_port_pub("out", m);
+            n_pub++;
+            at += rec;
+        }
+    }
+    return n_pub;
 }
 
 void block::message_port_pub(const std::string &port, const pdu_t &m)
@@ -76,6 +120,8 @@ gpu_session::~gpu_session()
     if (!d_ctx) return;
     for (dbuf &b : d_buf)
         if (b.p) gr80211_dev_free(d_ctx, b.p);
+    for (dbuf &b : d_stage)
+        if (b.p) gr80211_host_free(d_ctx, b.p);
     gr80211_destroy(d_ctx);
 }
 
@@ -90,6 +136,71 @@ void *gpu_session::buffer(int slot, size_t bytes)
     return b.p;
 }
 
+void *gpu_session::staging(int slot, size_t bytes)
+{
+    dbuf &b = d_stage[slot];
+    if (bytes <= b.cap) return b.p;
+    if (b.p) gr80211_host_free(d_ctx, b.p);
+    b.cap = bytes + bytes / 4 + 4096;
+    b.p = d_ctx ? gr80211_host_alloc(d_ctx, b.cap) : nullptr;
+    if (!b.p) b.cap = 0;
+    return b.p;
+}
+
+device_fifo::~device_fifo()
+{
+    if (!d_g.ok()) return;
+    if (d_p) gr80211_dev_free(d_g.ctx(), d_p);
+    if (d_alt) gr80211_dev_free(d_g.ctx(), d_alt);
+}
+
+bool device_fifo::reserve(size_t items)
+{
+    if (items <= d_cap) return true;
+    if (!d_g.ok()) return false;
+    size_t cap = std::max<size_t>(2 * d_cap, items);
+    cap = std::max<size_t>(cap, (size_t)1 << 20);
+    char *q = static_cast<char *>(gr80211_dev_alloc(d_g.ctx(), (cap + 64) * d_item));
+    if (!q) return false;
+    if (d_n && gr80211_copy_d2d(d_g.ctx(), q, d_p, d_n * d_item, nullptr) != GR80211_OK) {
+        gr80211_dev_free(d_g.ctx(), q);
+        return false;
+    }
+    if (d_p) gr80211_dev_free(d_g.ctx(), d_p);
+    if (d_alt) gr80211_dev_free(d_g.ctx(), d_alt);
+    d_alt = nullptr;
+    d_p = q;
+    d_cap = cap;
+    return true;
+}
+
+bool device_fifo::append(const void *host_src, size_t items)
+{
+    if (items == 0) return true;
+    if (!reserve(d_n + items)) return false;
+    if (gr80211_copy_h2d(d_g.ctx(), d_p + d_n * d_item, host_src, items * d_item, nullptr) != GR80211_OK) return false;
+    d_n += items;
+    return true;
+}
+
+bool device_fifo::release_front(size_t items)
+{
+    if (items >= d_n) {
+        d_n = 0;
+        return true;
+    }
+    if (items == 0) return true;
+    // the rest moves to the front of the other buffer (a copy inside one buffer could overlap)
+    if (!d_alt) {
+        d_alt = static_cast<char *>(gr80211_dev_alloc(d_g.ctx(), (d_cap + 64) * d_item));
+        if (!d_alt) return false;
+    }
+    if (gr80211_copy_d2d(d_g.ctx(), d_alt, d_p + items * d_item, (d_n - items) * d_item, nullptr) != GR80211_OK) return false;
+    std::swap(d_p, d_alt);
+    d_n -= items;
+    return true;
+}
+
 std::string gpu_session::error() const { return d_ctx ? gr80211_last_error(d_ctx) : "no GPU context"; }
 
 // ------------------------------------------------------------------------------------ decode
@@ -99,7 +210,7 @@ decode::sptr decode::make(bool ifdebug, int batch_frames, int device)
 }
 
 decode::decode(bool ifdebug, int batch_frames, int device)
-    : block(1), d_debug(ifdebug), d_batch(batch_frames < 1 ? 1 : batch_frames), d_gpu(device)
+    : block(1), d_debug(ifdebug), d_batch(batch_frames < 1 ? 1 : batch_frames), d_gpu(device), d_llr(d_gpu, sizeof(float))
 {
     if (!d_gpu.ok()) d_err = "gr80211_create failed";
 }
@@ -188,7 +299,11 @@ int decode::general_work(int, gr_vector_int &ninput_items, gr_vector_const_void_
         if (d_state == S_COLLECT || d_state == S_CLEAN) {
             const long need = t_nTotal - t_nProcd;
             const int take = (int)std::min<long>(need < 0 ? 0 : need, n - used);
-            if (d_state == S_COLLECT) d_llr.insert(d_llr.end(), in + used, in + used + take);
+            if (d_state == S_COLLECT && !d_llr.append(in + used, (size_t)take)) {
+                d_err = "upload of the soft bits failed: " + d_gpu.error();
+                consume_each(used);
+                return 0;
+            }
             t_nProcd += take;
             used += take;
             if (t_nProcd >= t_nTotal) {
@@ -209,7 +324,7 @@ bool decode::flush()
 {
     // a packet cut off by the end of the stream is dropped, as the reference never finishes it either
     if (d_state == S_COLLECT && !d_desc.empty()) {
-        d_llr.resize((size_t)d_desc.back().llr_off);
+        d_llr.truncate((size_t)d_desc.back().llr_off);
         d_desc.pop_back();
     }
     d_state = S_IDLE;
@@ -223,7 +338,7 @@ bool decode::run_batch()
     if (n <= 0) return true;
     if (!d_gpu.ok()) return false;
     const size_t nfl = d_llr.size();
-    void *dl = d_gpu.buffer(0, (nfl + 64) * sizeof(float));
+    const void *dl = d_llr.data();  // uploaded window by window as the stream came in
     uint8_t *dout = static_cast<uint8_t *>(d_gpu.buffer(1, (size_t)n * OUT_STRIDE));
     int32_t *dlen = static_cast<int32_t *>(d_gpu.buffer(2, (size_t)n * 4));
     int32_t *dnp = static_cast<int32_t *>(d_gpu.buffer(3, (size_t)n * 4));
@@ -232,31 +347,20 @@ bool decode::run_batch()
         return false;
     }
     gr80211_ctx *c = d_gpu.ctx();
-    std::vector<uint8_t> out((size_t)n * OUT_STRIDE);
-    std::vector<int32_t> len(n);
-    if (gr80211_copy_h2d(c, dl, d_llr.data(), nfl * sizeof(float), nullptr) != GR80211_OK ||
-        gr80211_decode_batch(c, static_cast<const float *>(dl), nfl, d_desc.data(), n, 0, dout, OUT_STRIDE, dlen, dnp,
+    uint8_t *out = static_cast<uint8_t *>(d_gpu.staging(0, (size_t)n * OUT_STRIDE));
+    int32_t *len = static_cast<int32_t *>(d_gpu.staging(1, (size_t)n * 4));
+    if (!out || !len) {
+        d_err = "page-locked host memory exhausted";
+        return false;
+    }
+    if (gr80211_decode_batch(c, static_cast<const float *>(dl), nfl, d_desc.data(), n, 0, dout, OUT_STRIDE, dlen, dnp,
                              nullptr, 0, nullptr) != GR80211_OK ||
-        gr80211_copy_d2h(c, len.data(), dlen, (size_t)n * 4, nullptr) != GR80211_OK ||
-        gr80211_copy_d2h(c, out.data(), dout, out.size(), nullptr) != GR80211_OK) {
+        gr80211_copy_d2h(c, len, dlen, (size_t)n * 4, nullptr) != GR80211_OK ||
+        gr80211_copy_d2h(c, out, dout, (size_t)n * OUT_STRIDE, nullptr) != GR80211_OK) {
         d_err = d_gpu.error();
         return false;
     }
-    for (int i = 0; i < n; i++) {
-        // a slot holds the frame's messages back to back: [format][len lo][len hi][MPDU][mcs]
-        const uint8_t *p = &out[(size_t)i * OUT_STRIDE];
-        int at = 0;
-        while (at + 4 <= len[i]) {
-            const int L = p[at + 1] | (p[at + 2] << 8);
-            pdu_t m;
-            const int rec = L + (p[at] == F_VHT_CHAN ? 3 : 4);  // a channel message has no trailing mcs byte
-            m.blob.assign(p + at, p + at + rec);
-            m.len = rec;
-            message_port_pub("out", m);
-            d_nPdu++;
-            at += rec;
-        }
-    }
+    d_nPdu += publish_slots(out, len, n, OUT_STRIDE);
     d_llr.clear();
     d_desc.clear();
     return true;
@@ -267,7 +371,7 @@ rx::sptr rx::make(int n_rx, int batch_frames, int device) { return sptr(new rx(n
 
 rx::rx(int n_rx, int batch_frames, int device)
     : block(n_rx == 2 ? 3 : 2), d_nrx(n_rx == 2 ? 2 : 1), d_batch(batch_frames < 1 ? 1 : batch_frames), d_gpu(device),
-      d_maxHold((size_t)1 << 22)
+      d_hold0(d_gpu, sizeof(gr_complex)), d_hold1(d_gpu, sizeof(gr_complex)), d_maxHold((size_t)1 << 22)
 {
     if (!d_gpu.ok()) d_err = "gr80211_create failed";
 }
@@ -285,8 +389,7 @@ int rx::general_work(int, gr_vector_int &ninput_items, gr_vector_const_void_star
     int n = std::min(ninput_items[0], ninput_items[1]);
     if (d_nrx == 2) n = std::min(n, ninput_items[2]);
     std::vector<tag_t> tags;
-    for (int i = 0; i < n; i++) {
-        if (!sync[i]) continue;
+    for (int i = next_set(sync, 0, n); i < n; i = next_set(sync, i + 1, n)) {
         const uint64_t at = nitems_read(0) + (uint64_t)i;
         get_tags_in_range(tags, 0, at, at + 1);
         if (tags.empty()) continue;  // "input sync with no tag" (lib/signal_impl.cc:96-100): not a trigger
@@ -303,7 +406,7 @@ int rx::general_work(int, gr_vector_int &ninput_items, gr_vector_const_void_star
     }
     // samples are only held from the first pending trigger on
     int from = 0;
-    if (d_hold[0].empty()) {
+    if (d_hold0.empty()) {
         if (d_trig.empty()) {
             from = n;
         } else {
@@ -314,10 +417,14 @@ int rx::general_work(int, gr_vector_int &ninput_items, gr_vector_const_void_star
     }
     for (int a = 0; a < d_nrx; a++) {
         const gr_complex *s = static_cast<const gr_complex *>(input_items[1 + a]);
-        d_hold[a].insert(d_hold[a].end(), s + from, s + n);
+        if (!hold(a).append(s + from, (size_t)(n - from))) {
+            d_err = "upload of the samples failed: " + d_gpu.error();
+            consume_each(0);
+            return 0;
+        }
     }
     consume_each(n);
-    if ((int)d_trig.size() >= d_batch || d_hold[0].size() >= d_maxHold) process(false);
+    if ((int)d_trig.size() >= d_batch || d_hold0.size() >= d_maxHold) process(false);
     return 0;
 }
 
@@ -327,7 +434,7 @@ bool rx::flush() { return process(true); }
 // `signal` over them in stream order, decode the frames whose samples are complete, release what is done.
 bool rx::process(bool final)
 {
-    const uint64_t held_end = d_base + d_hold[0].size();
+    const uint64_t held_end = d_base + d_hold0.size();
     // triggers at or behind the search position can never start a frame
     {
         size_t k = 0;
@@ -337,24 +444,16 @@ bool rx::process(bool final)
     if (d_trig.empty()) {
         // nothing pending: everything held so far can go
         d_cursor = std::max(d_cursor, held_end);
-        for (int a = 0; a < d_nrx; a++) d_hold[a].clear();
+        for (int a = 0; a < d_nrx; a++) hold(a).clear();
         d_base = held_end;
         return true;
     }
     if (!d_gpu.ok()) return false;
     gr80211_ctx *c = d_gpu.ctx();
-    const size_t nheld = d_hold[0].size();
-    void *diq0 = d_gpu.buffer(0, (nheld + 64) * sizeof(gr_complex));
-    void *diq1 = d_nrx == 2 ? d_gpu.buffer(1, (nheld + 64) * sizeof(gr_complex)) : nullptr;
-    if (!diq0 || (d_nrx == 2 && !diq1)) {
-        d_err = "device allocation failed";
-        return false;
-    }
-    if (gr80211_copy_h2d(c, diq0, d_hold[0].data(), nheld * sizeof(gr_complex), nullptr) != GR80211_OK ||
-        (d_nrx == 2 && gr80211_copy_h2d(c, diq1, d_hold[1].data(), nheld * sizeof(gr_complex), nullptr) != GR80211_OK)) {
-        d_err = d_gpu.error();
-        return false;
-    }
+    const size_t nheld = d_hold0.size();
+    // the samples are on the device already: every window was uploaded when it arrived
+    const void *diq0 = d_hold0.data();
+    const void *diq1 = d_nrx == 2 ? d_hold1.data() : nullptr;
 
     // ---- 1. spans: L-SIG of every trigger that has its 224 samples (lib/signal_impl.cc:108-131)
     std::vector<gr80211_frame_desc> pd;
@@ -432,31 +531,21 @@ bool rx::process(bool final)
         uint8_t *dout = static_cast<uint8_t *>(d_gpu.buffer(3, (size_t)nf * OUT_STRIDE));
         int32_t *dlen = static_cast<int32_t *>(d_gpu.buffer(4, (size_t)nf * 4));
         int32_t *dnp = static_cast<int32_t *>(d_gpu.buffer(5, (size_t)nf * 4));
-        std::vector<uint8_t> out((size_t)nf * OUT_STRIDE);
-        std::vector<int32_t> len(nf);
-        if (!dout || !dlen || !dnp ||
-            gr80211_rx_batch(c, diq0, diq1, nheld, fd.data(), nf, 0, dout, OUT_STRIDE, dlen, dnp, nullptr, nullptr) !=
+        uint8_t *out = static_cast<uint8_t *>(d_gpu.staging(0, (size_t)nf * OUT_STRIDE));
+        int32_t *len = static_cast<int32_t *>(d_gpu.staging(1, (size_t)nf * 4));
+        if (!dout || !dlen || !dnp || !out || !len) {
+            d_err = "allocation of the output buffers failed";
+            return false;
+        }
+        if (gr80211_rx_batch(c, diq0, diq1, nheld, fd.data(), nf, 0, dout, OUT_STRIDE, dlen, dnp, nullptr, nullptr) !=
                 GR80211_OK ||
-            gr80211_copy_d2h(c, len.data(), dlen, (size_t)nf * 4, nullptr) != GR80211_OK ||
-            gr80211_copy_d2h(c, out.data(), dout, out.size(), nullptr) != GR80211_OK) {
+            gr80211_copy_d2h(c, len, dlen, (size_t)nf * 4, nullptr) != GR80211_OK ||
+            gr80211_copy_d2h(c, out, dout, (size_t)nf * OUT_STRIDE, nullptr) != GR80211_OK) {
             d_err = d_gpu.error();
             return false;
         }
         d_nFrames += (uint64_t)nf;
-        for (int i = 0; i < nf; i++) {
-            const uint8_t *p = &out[(size_t)i * OUT_STRIDE];
-            int at = 0;
-            while (at + 4 <= len[i]) {
-                const int L = p[at + 1] | (p[at + 2] << 8);
-                pdu_t m;
-                const int rec = L + (p[at] == F_VHT_CHAN ? 3 : 4);  // a channel message has no trailing mcs byte
-                m.blob.assign(p + at, p + at + rec);
-                m.len = rec;
-                message_port_pub("out", m);
-                d_nPdu++;
-                at += rec;
-            }
-        }
+        d_nPdu += publish_slots(out, len, nf, OUT_STRIDE);
     }
 
     // ---- 4. release settled triggers and the samples nothing pending can need
@@ -465,7 +554,11 @@ bool rx::process(bool final)
     if (!d_trig.empty() && !final) keep_from = std::min(keep_from, std::max(d_trig[0].pos, d_base));
     if (final) d_trig.clear();
     const size_t drop = (size_t)(keep_from - d_base);
-    for (int a = 0; a < d_nrx; a++) d_hold[a].erase(d_hold[a].begin(), d_hold[a].begin() + (long)drop);
+    for (int a = 0; a < d_nrx; a++)
+        if (!hold(a).release_front(drop)) {
+            d_err = "release of the held samples failed: " + d_gpu.error();
+            return false;
+        }
     d_base = keep_from;
     return true;
 }
@@ -473,7 +566,9 @@ bool rx::process(bool final)
 // ------------------------------------------------------------------------------------ capture_rx
 capture_rx::sptr capture_rx::make(int n_rx, int device) { return sptr(new capture_rx(n_rx, device)); }
 
-capture_rx::capture_rx(int n_rx, int device) : block(n_rx == 2 ? 2 : 1), d_nrx(n_rx == 2 ? 2 : 1), d_gpu(device)
+capture_rx::capture_rx(int n_rx, int device)
+    : block(n_rx == 2 ? 2 : 1), d_nrx(n_rx == 2 ? 2 : 1), d_gpu(device), d_hold0(d_gpu, sizeof(gr_complex)),
+      d_hold1(d_gpu, sizeof(gr_complex))
 {
     if (!d_gpu.ok()) d_err = "gr80211_create failed";
 }
@@ -491,7 +586,11 @@ int capture_rx::general_work(int, gr_vector_int &ninput_items, gr_vector_const_v
     if (d_nrx == 2) n = std::min(n, ninput_items[1]);
     for (int a = 0; a < d_nrx; a++) {
         const gr_complex *s = static_cast<const gr_complex *>(input_items[a]);
-        d_hold[a].insert(d_hold[a].end(), s, s + n);
+        if (!hold(a).append(s, (size_t)n)) {
+            d_err = "upload of the samples failed: " + d_gpu.error();
+            consume_each(0);
+            return 0;
+        }
     }
     consume_each(n);
     return 0;
@@ -499,52 +598,41 @@ int capture_rx::general_work(int, gr_vector_int &ninput_items, gr_vector_const_v
 
 bool capture_rx::flush()
 {
-    const size_t n = d_hold[0].size();
+    const size_t n = d_hold0.size();
     if (n == 0) return true;
     if (!d_gpu.ok()) return false;
     gr80211_ctx *c = d_gpu.ctx();
-    void *diq0 = d_gpu.buffer(0, (n + 64) * sizeof(gr_complex));
-    void *diq1 = d_nrx == 2 ? d_gpu.buffer(1, (n + 64) * sizeof(gr_complex)) : nullptr;
+    const void *diq0 = d_hold0.data();
+    const void *diq1 = d_nrx == 2 ? d_hold1.data() : nullptr;
     // a frame needs at least 400 samples of preamble; sync bytes whose L-SIG check fails also take a slot
     const int max_frames = (int)std::min<size_t>(n / 80 + 16, (size_t)1 << 20);
     uint8_t *dout = static_cast<uint8_t *>(d_gpu.buffer(3, (size_t)max_frames * OUT_STRIDE));
     int32_t *dlen = static_cast<int32_t *>(d_gpu.buffer(4, (size_t)max_frames * 4));
     int32_t *dnp = static_cast<int32_t *>(d_gpu.buffer(5, (size_t)max_frames * 4));
-    if (!diq0 || (d_nrx == 2 && !diq1) || !dout || !dlen || !dnp) {
+    if (!dout || !dlen || !dnp) {
         d_err = "device allocation failed";
         return false;
     }
     int nf = 0;
-    if (gr80211_copy_h2d(c, diq0, d_hold[0].data(), n * sizeof(gr_complex), nullptr) != GR80211_OK ||
-        (d_nrx == 2 && gr80211_copy_h2d(c, diq1, d_hold[1].data(), n * sizeof(gr_complex), nullptr) != GR80211_OK) ||
-        gr80211_set_mu_pos(c, d_muPos) != GR80211_OK ||
+    if (gr80211_set_mu_pos(c, d_muPos) != GR80211_OK ||
         gr80211_rx_capture(c, diq0, diq1, n, dout, OUT_STRIDE, dlen, dnp, max_frames, nullptr, &nf, nullptr) != GR80211_OK) {
         d_err = d_gpu.error();
         return false;
     }
-    std::vector<uint8_t> out((size_t)nf * OUT_STRIDE);
-    std::vector<int32_t> len(nf);
-    if (nf > 0 && (gr80211_copy_d2h(c, len.data(), dlen, (size_t)nf * 4, nullptr) != GR80211_OK ||
-                   gr80211_copy_d2h(c, out.data(), dout, out.size(), nullptr) != GR80211_OK)) {
+    uint8_t *out = static_cast<uint8_t *>(d_gpu.staging(0, (size_t)nf * OUT_STRIDE + 1));
+    int32_t *len = static_cast<int32_t *>(d_gpu.staging(1, (size_t)nf * 4 + 4));
+    if (!out || !len) {
+        d_err = "page-locked host memory exhausted";
+        return false;
+    }
+    if (nf > 0 && (gr80211_copy_d2h(c, len, dlen, (size_t)nf * 4, nullptr) != GR80211_OK ||
+                   gr80211_copy_d2h(c, out, dout, (size_t)nf * OUT_STRIDE, nullptr) != GR80211_OK)) {
         d_err = d_gpu.error();
         return false;
     }
     d_nFrames += (uint64_t)nf;
-    for (int i = 0; i < nf; i++) {
-        const uint8_t *p = &out[(size_t)i * OUT_STRIDE];
-        int at = 0;
-        while (at + 4 <= len[i]) {
-            const int L = p[at + 1] | (p[at + 2] << 8);
-            pdu_t m;
-            const int rec = L + (p[at] == F_VHT_CHAN ? 3 : 4);  // a channel message has no trailing mcs byte
-            m.blob.assign(p + at, p + at + rec);
-            m.len = rec;
-            message_port_pub("out", m);
-            d_nPdu++;
-            at += rec;
-        }
-    }
-    for (int a = 0; a < d_nrx; a++) d_hold[a].clear();
+    d_nPdu += publish_slots(out, len, nf, OUT_STRIDE);
+    for (int a = 0; a < d_nrx; a++) hold(a).clear();
     return true;
 }
 

@@ -16,6 +16,7 @@
 
 #include <complex>
 #include <cstdint>
+#include <deque>
 #include <functional>
 #include <memory>
 #include <string>
@@ -56,7 +57,7 @@ public:
     virtual bool flush() { return true; }
 
     // ---- scheduler side
-    void add_item_tag_in(int port, const tag_t &t);  // tags must arrive in non-decreasing offset order per port
+    void add_item_tag_in(int port, const tag_t &t);  // any order; cheapest in non-decreasing offset order
     void clear_item_tags_in() { for (auto &tv : d_tags) tv.clear(); }
     void set_msg_handler(std::function<void(const std::string &port, const pdu_t &msg)> f) { d_handler = std::move(f); }
     uint64_t nitems_read(int port) const { return d_read[port]; }
@@ -69,11 +70,13 @@ protected:
     void consume_each(int n) { d_consumed = n; }
     void get_tags_in_range(std::vector<tag_t> &v, int port, uint64_t start, uint64_t end) const;
     void message_port_pub(const std::string &port, const pdu_t &m);
+    // Publishes the messages n frame slots hold (stride bytes apart, len[i] bytes used); returns how many.
+    uint64_t publish_slots(const uint8_t *out, const int32_t *len, int n, int stride);
     std::string d_err;
 
 private:
     std::vector<uint64_t> d_read;
-    std::vector<std::vector<tag_t>> d_tags;
+    std::vector<std::deque<tag_t>> d_tags;  // per port, sorted by offset; passed tags leave at the front
     int d_consumed = 0;
     std::function<void(const std::string &, const pdu_t &)> d_handler;
 };
@@ -92,6 +95,7 @@ public:
     void set_ampdu_strict(bool on) { if (d_ctx) gr80211_set_ampdu_strict(d_ctx, on ? 1 : 0); }
     gr80211_ctx *ctx() const { return d_ctx; }
     void *buffer(int slot, size_t bytes);  // device buffer `slot` of at least `bytes` (contents not preserved)
+    void *staging(int slot, size_t bytes);  // page-locked host buffer `slot`, same rules
     std::string error() const;
 
 private:
@@ -101,6 +105,32 @@ private:
         size_t cap = 0;
     };
     dbuf d_buf[8];
+    dbuf d_stage[4];
+};
+
+// Items waiting for the GPU, kept in device memory: every window of the stream is uploaded when it arrives, so the
+// host holds no copy.  Append at the back, release at the front.
+class device_fifo
+{
+public:
+    device_fifo(gpu_session &g, size_t item_bytes) : d_g(g), d_item(item_bytes) {}
+    ~device_fifo();
+    device_fifo(const device_fifo &) = delete;
+    device_fifo &operator=(const device_fifo &) = delete;
+    size_t size() const { return d_n; }
+    bool empty() const { return d_n == 0; }
+    const void *data() const { return d_p; }    // device pointer; 64 spare items follow the last one
+    bool append(const void *host_src, size_t items);  // false on a GPU error (see gpu_session::error())
+    bool release_front(size_t items);
+    void truncate(size_t items) { if (items < d_n) d_n = items; }
+    void clear() { d_n = 0; }
+
+private:
+    bool reserve(size_t items);
+    gpu_session &d_g;
+    size_t d_item;
+    char *d_p = nullptr, *d_alt = nullptr;  // d_alt: same capacity, target of release_front's move (made on demand)
+    size_t d_n = 0, d_cap = 0;              // in items
 };
 
 class decode : public block
@@ -132,7 +162,7 @@ private:
     // tags of the packet being collected (lib/decode_impl.cc:77-88)
     long t_format = 0, t_len = 0, t_nTotal = 0, t_cr = 0, t_mcs = 0, t_ampdu = 0, v_trellis = 0;
     long t_nProcd = 0;
-    std::vector<float> d_llr;                 // soft bits of the pending packets, back to back
+    device_fifo d_llr;                        // soft bits of the pending packets, back to back
     std::vector<gr80211_dec_desc> d_desc;     // one per pending packet
     uint64_t d_nSeen = 0, d_nPdu = 0;
 };
@@ -170,7 +200,8 @@ private:
     int d_nrx, d_batch;
     int d_muPos = 0;
     gpu_session d_gpu;
-    std::vector<gr_complex> d_hold[2];  // samples not yet released, both antennas
+    device_fifo d_hold0, d_hold1;         // samples not yet released, one queue per antenna
+    device_fifo &hold(int a) { return a ? d_hold1 : d_hold0; }
     uint64_t d_base = 0;                // absolute item index of d_hold[*][0]
     uint64_t d_cursor = 0;              // absolute index where the trigger search resumes (lib/signal_impl.cc:75-106)
     std::vector<trigger> d_trig;
@@ -204,7 +235,8 @@ private:
     int d_nrx;
     int d_muPos = 0;
     gpu_session d_gpu;
-    std::vector<gr_complex> d_hold[2];
+    device_fifo d_hold0, d_hold1;
+    device_fifo &hold(int a) { return a ? d_hold1 : d_hold0; }
     uint64_t d_nFrames = 0, d_nPdu = 0;
 };
 

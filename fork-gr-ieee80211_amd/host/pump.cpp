@@ -8,7 +8,10 @@
 //   gr80211_pump decode <chunk> <batch> <tags.txt> <llr.bin>
 //       tags.txt: one "offset format len total cr mcs ampdu trellis" line per packet; llr.bin: float32
 //
-// Output: "PDU <hex of the message blob>" per message, then "STAT ..." counters.  Exit code 0 on success.
+// Output: "PDU <hex of the message blob>" per message (not with GR80211_PUMP_QUIET=1 in the environment), then
+// "STAT ..." counters and the seconds spent between the first general_work call and the end of flush().
+// Exit code 0 on success.
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -32,8 +35,12 @@ static bool read_file(const char *path, std::vector<char> &out)
     return ok;
 }
 
+static bool g_quiet = false;
+static double g_seconds = 0.0;
+
 static void on_msg(const std::string &, const pdu_t &m)
 {
+    if (g_quiet) return;
     std::string hex;
     static const char *d = "0123456789abcdef";
     for (uint8_t b : m.blob) {
@@ -49,6 +56,7 @@ static bool pump(block &b, const std::vector<const char *> &ports, const std::ve
 {
     size_t at = 0;
     int idle = 0;
+    const auto t0 = std::chrono::steady_clock::now();
     while (at < n_items) {
         const int win = (int)std::min<size_t>((size_t)chunk, n_items - at);
         gr_vector_int nin(ports.size(), win);
@@ -73,11 +81,13 @@ static bool pump(block &b, const std::vector<const char *> &ports, const std::ve
         fprintf(stderr, "flush failed: %s\n", b.last_error().c_str());
         return false;
     }
+    g_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     return true;
 }
 
 int main(int argc, char **argv)
 {
+    if (const char *q = getenv("GR80211_PUMP_QUIET")) g_quiet = q[0] == '1';
     if (argc >= 7 && !strcmp(argv[1], "rx")) {
         const int n_rx = atoi(argv[2]), chunk = atoi(argv[3]), batch = atoi(argv[4]);
         std::vector<char> iq0, iq1;
@@ -113,6 +123,7 @@ int main(int argc, char **argv)
         const bool ok = pump(*b, ports, isz, n, chunk);
         printf("STAT triggers=%llu frames=%llu pdus=%llu\n", (unsigned long long)b->triggers_seen(),
                (unsigned long long)b->frames_decoded(), (unsigned long long)b->pdus_published());
+        printf("TIME items=%zu seconds=%.6f\n", n, g_seconds);
         return ok ? 0 : 1;
     }
     if (argc >= 5 && !strcmp(argv[1], "capture")) {
@@ -135,6 +146,7 @@ int main(int argc, char **argv)
         const bool ok = pump(*b, ports, isz, n, chunk);
         printf("STAT frames=%llu pdus=%llu\n", (unsigned long long)b->frames_decoded(),
                (unsigned long long)b->pdus_published());
+        printf("TIME items=%zu seconds=%.6f\n", n, g_seconds);
         return ok ? 0 : 1;
     }
     if (argc >= 6 && !strcmp(argv[1], "decode")) {
@@ -165,6 +177,7 @@ int main(int argc, char **argv)
         const bool ok = pump(*b, {llr.data()}, {4}, n, chunk);
         printf("STAT packets=%llu pdus=%llu\n", (unsigned long long)b->packets_seen(),
                (unsigned long long)b->pdus_published());
+        printf("TIME items=%zu seconds=%.6f\n", n, g_seconds);
         return ok ? 0 : 1;
     }
     fprintf(stderr, "usage: gr80211_pump rx <n_rx> <chunk> <batch> <triggers.txt> <iq0.bin> [iq1.bin]\n"

@@ -66,6 +66,7 @@ EXPORTS = [
     "gr80211_demod_batch", "gr80211_decode_batch", "gr80211_dev_alloc", "gr80211_dev_free",
     "gr80211_copy_h2d", "gr80211_copy_d2h", "gr80211_set_profiling", "gr80211_last_timing",
     "gr80211_version", "gr80211_table_checksum", "gr80211_tx_samples", "gr80211_tx_batch", "gr80211_set_mu_pos", "gr80211_set_ampdu_strict", "gr80211_tx_mu_batch",
+    "gr80211_host_alloc", "gr80211_host_free", "gr80211_copy_d2d",
 ]
 
 _lib = None
@@ -99,6 +100,11 @@ def load_library():
                                        C.c_int, vp]
     L.gr80211_dev_alloc.argtypes = [vp, C.c_size_t]
     L.gr80211_dev_alloc.restype = vp
+    L.gr80211_host_alloc.argtypes = [vp, C.c_size_t]
+    L.gr80211_host_alloc.restype = vp
+    L.gr80211_copy_d2d.argtypes = [vp, vp, vp, C.c_size_t, vp]
+    L.gr80211_host_free.argtypes = [vp, vp]
+    L.gr80211_host_free.restype = None
     L.gr80211_dev_free.argtypes = [vp, vp]
     L.gr80211_dev_free.restype = None
     L.gr80211_copy_h2d.argtypes = [vp, vp, vp, C.c_size_t, vp]

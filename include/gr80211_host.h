@@ -69,7 +69,7 @@ int gr80211_block_n_inputs(const gr80211_block *b);
 int gr80211_block_forecast(gr80211_block *b, int noutput_items, int *ninput_items_required, int n_inputs);
 /*
  * gr::block::general_work.  ninput_items / input_items: one entry per input port; tags: the tags inside the
- * offered windows (non-decreasing offsets per port; all of them with every call, as get_tags_in_range over the
+ * offered windows (in any order, cheapest by non-decreasing offset; all of them with every call, as get_tags_in_range over the
  * window returns them: the block keeps no tag between calls).  *consumed receives what consume_each() was called with.
  * Returns the items produced (always 0: there is no stream output) or a negative value on error.
  */

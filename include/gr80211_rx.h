@@ -268,6 +268,13 @@ void *gr80211_dev_alloc(gr80211_ctx *ctx, size_t bytes);
 void gr80211_dev_free(gr80211_ctx *ctx, void *p);
 int gr80211_copy_h2d(gr80211_ctx *ctx, void *d_dst, const void *h_src, size_t bytes, void *stream);
 int gr80211_copy_d2h(gr80211_ctx *ctx, void *h_dst, const void *d_src, size_t bytes, void *stream);
+int gr80211_copy_d2d(gr80211_ctx *ctx, void *d_dst, const void *d_src, size_t bytes, void *stream); /* no overlap */
+/*
+ * Page-locked host memory: copies to and from it run at the full rate of the link, copies from ordinary memory at
+ * a fraction of it.  NULL when the allocation fails.
+ */
+void *gr80211_host_alloc(gr80211_ctx *ctx, size_t bytes);
+void gr80211_host_free(gr80211_ctx *ctx, void *p);
 
 /*
  * Timing of the last batch call, measured with HIP events on the stream the kernels ran on.

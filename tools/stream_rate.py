@@ -1,0 +1,75 @@
+"""Rate of the streaming host blocks on host-resident streams: a corpus of VHT MCS8 frames is made with the GPU
+transmitter and written to files, then the command-line scheduler (gr80211_pump) plays it through the `rx` block
+(sync bytes + tags, as `sync` hands them to `signal`), through `capture_rx` (antenna stream only) and, as soft
+bits, through `decode`, in scheduler-sized windows.  The figures include everything a flowgraph pays: window
+copies, host-to-device transfers, the trigger search, messages; reading the files is outside the timed part.
+    python3 tools/stream_rate.py [frames] [workdir]"""
+import importlib
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+PUMP = os.path.join(ROOT, "fork-gr-ieee80211_amd", "gr80211_pump")
+
+
+def run(args, n_samples, label):
+    env = dict(os.environ, GR80211_PUMP_QUIET="1")
+    p = subprocess.run([PUMP] + [str(a) for a in args], capture_output=True, text=True, env=env, timeout=300)
+    stat = [l for l in p.stdout.splitlines() if l.startswith("STAT")]
+    tm = [l for l in p.stdout.splitlines() if l.startswith("TIME")]
+    if p.returncode != 0 or not tm:
+        print(label, "failed", p.returncode, p.stderr[-500:], flush=True)
+        return
+    sec = float(tm[0].split("seconds=")[1])
+    print("%-34s %s  %.3f s  %.1f Msamples/s" % (label, stat[0], sec, n_samples / sec / 1e6), flush=True)
+
+
+def main():
+    import torch
+    import bench
+    pkg = importlib.import_module("fork-gr-ieee80211_amd")
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 4000
+    work = sys.argv[2] if len(sys.argv) > 2 else "/tmp/stream_rate"
+    os.makedirs(work, exist_ok=True)
+    dev = torch.device("cuda:0")
+    ctx = pkg.RxContext(0)
+    arenas, sync, navail, exp, idx, L, _ = bench.build_corpus_gpu(torch, ctx, pkg.txgen, "vht_mcs8_1500B_snr30", n, 0, dev)
+    iq_t = arenas[0][: n * L + 64]
+    iq_t[n * L:] = 0
+    iq = iq_t.cpu().numpy()
+    f_iq = os.path.join(work, "iq0.bin")
+    iq.tofile(f_iq)
+    f_tr = os.path.join(work, "trig.txt")
+    with open(f_tr, "w") as fh:
+        for p in sync.tolist():
+            fh.write("%d 0.0 30.0 -40.0\n" % p)
+    # the soft bits `demod` would hand to `decode`, with the tags of each packet's first item
+    info, llr = ctx.demod_batch(iq_t, None, ctx.make_desc(sync, navail), n)
+    f_llr = os.path.join(work, "llr.bin")
+    np.asarray(llr).astype(np.float32).tofile(f_llr)
+    f_tg = os.path.join(work, "tags.txt")
+    with open(f_tg, "w") as fh:
+        for i in range(n):
+            fh.write("%d %d %d %d %d %d %d %d\n" % (int(info["llr_off"][i]), int(info["format"][i]), int(info["len"][i]),
+                                                  int(info["total"][i]), int(info["cr"][i]), int(info["mcs"][i]),
+                                                  int(info["ampdu"][i]), int(info["trellis"][i])))
+    ctx.close()
+    del arenas, iq_t
+    torch.cuda.empty_cache()
+    ns = n * L
+    print("%d VHT MCS8 frames, %d samples per antenna, %.0f MB of IQ" % (n, ns, ns * 8 / 1e6), flush=True)
+    for chunk, batch in ((8192, 4096), (65536, 4096), (65536, 16384), (1 << 20, 16384)):
+        run(["rx", 1, chunk, batch, f_tr, f_iq], ns, "rx      window %7d batch %5d" % (chunk, batch))
+    run(["capture", 1, 65536, f_iq], ns, "capture window   65536")
+    for chunk, batch in ((65536, 4096), (1 << 20, 16384)):
+        run(["decode", chunk, batch, f_tg, f_llr], ns, "decode  window %7d batch %5d" % (chunk, batch))
+    for f in (f_iq, f_tr, f_llr, f_tg):
+        os.remove(f)
+
+
+if __name__ == "__main__":
+    main()
