@@ -1005,18 +1005,67 @@ __device__ __forceinline__ void put_llrs(float *stage, c32 q, int mod, float sca
     }
 }
 
-// The wave's staged symbol -> the frame's LLR run, 16 bytes per lane (runs are 16-byte aligned:
-// every frame's soft-bit count is a multiple of 4).
+// The wave's staged symbol -> the frame's LLR run, 16 bytes per lane (runs are 16-byte aligned: every frame's
+// soft-bit count is a multiple of 4).  Always P store instructions, whatever the symbol's size: lanes past the
+// end repeat the last four soft bits (the same bytes to the same place).  With a fixed number of stores behind
+// it, the wait for the next symbol's prefetched samples can leave them in flight.
+template <int P>
 __device__ __forceinline__ void flush_stage(const float *stage, float *dst, int ncbps, int lane)
 {
     __builtin_amdgcn_wave_barrier();
-    for (int i = lane * 4; i < ncbps; i += 256) {
-        const float4 v = *reinterpret_cast<const float4 *>(stage + i);
-        *reinterpret_cast<float4 *>(dst + i) = v;
+    float4 v[P];
+    int at[P];
+#pragma unroll
+    for (int p = 0; p < P; p++) {
+        const int i = lane * 4 + p * 256;
+        at[p] = i < ncbps ? i : ncbps - 4;
+        v[p] = *reinterpret_cast<const float4 *>(stage + at[p]);
     }
+#pragma unroll
+    for (int p = 0; p < P; p++) *reinterpret_cast<float4 *>(dst + at[p]) = v[p];
     __builtin_amdgcn_wave_barrier();
 }
 
+// Sample k of the stream `demod` sees, as it lies in memory; src points at that stream's sample 0 (or, for a frame
+// without any, at some sample of the arena).  The load is issued whatever k is, so that every symbol costs the
+// same number of memory instructions; samples past nvalid read as zero (lib/signal_impl.cc:164-202 forwards
+// only what arrived).
+__device__ __forceinline__ c32 fetch_samp(const c32 *src, int k, int nvalid)
+{
+    const c32 v = src[k < nvalid ? k : 0];
+    return k < nvalid ? v : mk(0.0f, 0.0f);
+}
+
+// exp(j*(k+224)*rad): the CFO derotation `signal` applies to sample k of that stream (lib/signal_impl.cc:172-173).
+__device__ __forceinline__ c32 derot(int k, float rad)
+{
+    if (rad == 0.0f) return mk(1.0f, 0.0f);
+    float sn, cs;
+    sincosf((float)(k + 224) * rad, &sn, &cs);
+    return mk(cs, sn);
+}
+
+// 64-point DFT as wave_fft64, with this lane's five twiddles handed in (they do not change from symbol to symbol).
+__device__ __forceinline__ c32 wave_fft64_tw(c32 x, int lane, const c32 (&tw)[5])
+{
+#pragma unroll
+    for (int s = 0; s < 6; s++) {
+        const int half = 32 >> s;
+        c32 o = mk(__shfl_xor(x.x, half), __shfl_xor(x.y, half));
+        const bool up = (lane & half) != 0;
+        c32 lo = up ? o : x;
+        c32 hi = up ? x : o;
+        c32 sum = cadd(lo, hi), dif = csub(lo, hi);
+        if (s < 5) dif = cmul(dif, tw[s]);
+        x = up ? dif : sum;
+    }
+    return x;
+}
+
+// One workgroup per frame; the instantiation for the frame's number of spatial streams does the work, the other
+// one leaves at once (two kernels keep the one-stream path's registers, and with them its occupancy, free of the
+// 2x2 channel matrices).
+template <int NSS>
 __global__ __launch_bounds__(64 * DEMOD_WAVES) void k_demod(const c32 *__restrict__ iq0, const c32 *__restrict__ iq1,
                                                             uint64_t arena_len,
                                                             const gr80211_frame_desc *__restrict__ descs, int n,
@@ -1028,7 +1077,8 @@ __global__ __launch_bounds__(64 * DEMOD_WAVES) void k_demod(const c32 *__restric
     if (f >= n) return;
     const int st = info[f].status;
     if (!(st == GR80211_ST_OK || st == GR80211_ST_DROP_DECODE_LIMIT)) return;
-    __shared__ __attribute__((aligned(16))) float s_stage[DEMOD_WAVES][DEMOD_STAGE];
+    if ((info[f].nSS == 1) != (NSS == 1)) return;
+    __shared__ __attribute__((aligned(16))) float s_stage[DEMOD_WAVES][DEMOD_STAGE / 2 * NSS];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // symbol counters stay scalar
     const int bin = brev6(lane);
@@ -1037,16 +1087,16 @@ __global__ __launch_bounds__(64 * DEMOD_WAVES) void k_demod(const c32 *__restric
     const gr80211_frame_desc d = descs[f];
     uint64_t so;
     const int navail = frame_window(d, arena_len, &so);
-    const c32 *in0 = iq0 + so;
-    const c32 *in1 = iq1 ? iq1 + so : nullptr;
     const float rad = d.rad;
     int nvalid = fi.nsamp;
     if (nvalid > navail - 224) nvalid = navail - 224;
+    // a frame that got this far has its 224 preamble samples; one without data samples still needs an address
+    const uint64_t s0 = nvalid > 0 ? so + 224 : so;
+    const c32 *in0 = iq0 + s0;
 
-    const int fmt = fi.format, nss = fi.nSS, nb = fi.nBPSCS, ncbps = fi.nCBPS, mod = fi.mod;
+    const int fmt = fi.format, nb = fi.nBPSCS, ncbps = fi.nCBPS, mod = fi.mod;
     const bool legacy = fmt == GR80211_F_L;
     const bool used = legacy ? (c_tab.ltf_l[bin] != 0.0f) : (c_tab.ltf_nl[bin] != 0.0f);
-    const bool pil = is_pilot_bin(bin);
     const int jd = legacy ? c_tab.data_idx_l[bin] : c_tab.data_idx_nl[bin];
     const int pslot = bin == 43 ? 0 : bin == 57 ? 1 : bin == 7 ? 2 : 3;
     const int didx = nb == 1 ? 0 : nb == 2 ? 1 : nb == 4 ? 2 : nb == 6 ? 3 : 4;
@@ -1054,33 +1104,58 @@ __global__ __launch_bounds__(64 * DEMOD_WAVES) void k_demod(const c32 *__restric
     const int nax = nb == 1 ? 1 : nb / 2;  // bits per axis (BPSK: one bit, I axis only)
     float *out = llr + fi.llr_off;
     const int pp0 = legacy ? 1 : fmt == GR80211_F_HT ? 3 : 4;
+    const int nsym = fi.nSym, symsamp = fi.nSymSamp, data_off = fi.data_off;
 
-    if (nss == 1) {
+    // what does not change from symbol to symbol sits in registers before the loop starts: the twiddles, and
+    // the 127 pilot polarities spread over the lanes (lane l holds entries l and 64 + l)
+    c32 tw[5];
+#pragma unroll
+    for (int s = 0; s < 5; s++) {
+        const int k = (lane & ((32 >> s) - 1)) << s;
+        tw[s] = mk(c_tab.tw_re[k], c_tab.tw_im[k]);
+    }
+    const float pol0 = c_tab.pilot_p[lane], pol1 = c_tab.pilot_p[lane < 63 ? 64 + lane : 64];
+    asm volatile("; loop invariants resident" ::"v"(tw[0].x), "v"(tw[0].y), "v"(tw[1].x), "v"(tw[1].y), "v"(tw[2].x),
+                 "v"(tw[2].y), "v"(tw[3].x), "v"(tw[3].y), "v"(tw[4].x), "v"(tw[4].y), "v"(pol0), "v"(pol1));
+
+    if (NSS == 1) {
         const c32 h = chan1[(size_t)f * 64 + bin];
         const int16_t *map = legacy ? c_tab.deint_l[didx] : c_tab.deint_nl[didx];
         int kI[4], kQ[4];
         tone_slots(kI, kQ, map, jd, nb, nax, 0, 1, false);
-        c32 xn = load_samp(in0, fi.data_off + wave * fi.nSymSamp + SHIFT + lane, nvalid, rad);
-        for (int sym = wave; sym < fi.nSym; sym += DEMOD_WAVES) {
-            const c32 x = xn;
-            if (sym + DEMOD_WAVES < fi.nSym)  // next symbol's samples travel while this one is worked on
-                xn = load_samp(in0, fi.data_off + (sym + DEMOD_WAVES) * fi.nSymSamp + SHIFT + lane, nvalid, rad);
-            const c32 F = wave_fft64(x, lane);
+        asm volatile("; loop invariants resident" ::"v"(h.x), "v"(h.y), "v"(kI[0]), "v"(kI[1]), "v"(kI[2]), "v"(kI[3]),
+                     "v"(kQ[0]), "v"(kQ[1]), "v"(kQ[2]), "v"(kQ[3]));
+        int kn = data_off + wave * symsamp + SHIFT + lane;
+        c32 xn = fetch_samp(in0, kn, nvalid);
+        // the first symbol's samples are waited for here, so that inside the loop the only wait on memory is the
+        // one for the samples fetched a whole symbol earlier
+        asm volatile("; first symbol resident" ::"v"(xn.x), "v"(xn.y));
+        for (int sym = wave; sym < nsym; sym += DEMOD_WAVES) {
+            const c32 x = cmul(xn, derot(kn, rad));
+            // the next symbol's samples travel while this one is worked on (past the last symbol the load repeats
+            // an address that is valid anyway)
+            kn += DEMOD_WAVES * symsamp;
+            xn = fetch_samp(in0, kn, sym + DEMOD_WAVES < nsym ? nvalid : 0);
+            const c32 F = wave_fft64_tw(x, lane, tw);
             c32 e = mk(0.0f, 0.0f);
             if (used) e = cdiv(F, h);
             // pilot term of this lane's tone: sig * pilot * polarity (lib/demod_impl.cc:426-430);
             // base pattern {1,1,1,-1}, rotated one place per symbol for HT/VHT
-            const float pp = c_tab.pilot_p[(pp0 + sym) % 127];
+            const int pi = (pp0 + sym) % 127;
+            const float pp = __int_as_float(pi < 64 ? __builtin_amdgcn_readlane(__float_as_int(pol0), pi)
+                                                    : __builtin_amdgcn_readlane(__float_as_int(pol1), pi - 64));
             const int pr = legacy ? pslot : ((pslot + sym) & 3);
             const float pv = pr == 3 ? -1.0f : 1.0f;
             const c32 u = cmulf(cmulf(e, pv), pp);
             const c32 ps = cconj(cadd(cadd(cadd(lane_c<LN7>(u), lane_c<LN21>(u)), lane_c<LN43>(u)), lane_c<LN57>(u)));
             const float pa = cabs32(ps);
             if (jd >= 0) put_llrs(stage, cdivf(cmul(e, ps), pa), mod, scale, nb, nax, kI, kQ);
-            flush_stage(stage, out + (size_t)sym * ncbps, ncbps, lane);
+            flush_stage<2>(stage, out + (size_t)sym * ncbps, ncbps, lane);
         }
     } else {
         // two spatial streams on two antennas (lib/demod2_impl.cc:504-550, 586-628)
+        const c32 *in1 = iq1 + s0;
+        const bool pil = is_pilot_bin(bin);
         const c32 *c2 = chan2 + (size_t)f * CH2;
         c32 h[4], hi[4];
 #pragma unroll
@@ -1094,13 +1169,26 @@ __global__ __launch_bounds__(64 * DEMOD_WAVES) void k_demod(const c32 *__restric
         int kI1[4], kQ1[4], kI2[4], kQ2[4];
         tone_slots(kI1, kQ1, map1, jd, nb, nax, 0, sblk, true);
         tone_slots(kI2, kQ2, map2, jd, nb, nax, 1, sblk, true);
-        for (int sym = wave; sym < fi.nSym; sym += DEMOD_WAVES) {
-            const int off = fi.data_off + sym * fi.nSymSamp;
-            const c32 F1 = wave_fft64(load_samp(in0, off + SHIFT + lane, nvalid, rad), lane);
-            const c32 F2 = wave_fft64(load_samp(in1, off + SHIFT + lane, nvalid, rad), lane);
+        asm volatile("; loop invariants resident" ::"v"(h[0].x), "v"(h[1].x), "v"(h[2].x), "v"(h[3].x), "v"(hi[0].x),
+                     "v"(hi[1].x), "v"(hi[2].x), "v"(hi[3].x), "v"(pl1.x), "v"(pl2.x), "v"(kI1[3]), "v"(kQ1[3]),
+                     "v"(kI2[3]), "v"(kQ2[3]));
+        int kn = data_off + wave * symsamp + SHIFT + lane;
+        c32 xn1 = fetch_samp(in0, kn, nvalid), xn2 = fetch_samp(in1, kn, nvalid);
+        asm volatile("; first symbol resident" ::"v"(xn1.x), "v"(xn1.y), "v"(xn2.x), "v"(xn2.y));
+        for (int sym = wave; sym < nsym; sym += DEMOD_WAVES) {
+            const c32 rot = derot(kn, rad);
+            const c32 x1 = cmul(xn1, rot), x2 = cmul(xn2, rot);
+            kn += DEMOD_WAVES * symsamp;
+            const int nv = sym + DEMOD_WAVES < nsym ? nvalid : 0;
+            xn1 = fetch_samp(in0, kn, nv);
+            xn2 = fetch_samp(in1, kn, nv);
+            const c32 F1 = wave_fft64_tw(x1, lane, tw);
+            const c32 F2 = wave_fft64_tw(x2, lane, tw);
             c32 s1 = mk(0.0f, 0.0f), s2 = mk(0.0f, 0.0f);
             if (used) zf2(F1, F2, h, hi, s1, s2);
-            const float pp = c_tab.pilot_p[(pp0 + sym) % 127];
+            const int pi = (pp0 + sym) % 127;
+            const float pp = __int_as_float(pi < 64 ? __builtin_amdgcn_readlane(__float_as_int(pol0), pi)
+                                                    : __builtin_amdgcn_readlane(__float_as_int(pol1), pi - 64));
             const int pr = (pslot + sym) & 3;
             // PILOT_VHT {1,1,1,-1} on both streams; PILOT_HT_2_1 {1,1,-1,-1}, PILOT_HT_2_2 {1,-1,-1,1}
             const float pv1 = vht ? (pr == 3 ? -1.0f : 1.0f) : (pr >= 2 ? -1.0f : 1.0f);
@@ -1121,7 +1209,7 @@ __global__ __launch_bounds__(64 * DEMOD_WAVES) void k_demod(const c32 *__restric
                 put_llrs(stage, cdivf(cmul(s1, ps), pa), mod, scale, nb, nax, kI1, kQ1);
                 put_llrs(stage, cdivf(cmul(s2, ps), pa), mod, scale, nb, nax, kI2, kQ2);
             }
-            flush_stage(stage, out + (size_t)sym * ncbps, ncbps, lane);
+            flush_stage<4>(stage, out + (size_t)sym * ncbps, ncbps, lane);
         }
     }
 }
@@ -1687,8 +1775,12 @@ void launch_schedule(gr80211_frame_info *info, int n, int assign_llr, int32_t *s
 void launch_demod(const void *iq0, const void *iq1, uint64_t arena_len, const gr80211_frame_desc *desc, int n,
                   const gr80211_frame_info *info, const void *chan1, const void *chan2, float *llr, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_demod, dim3(n), dim3(256), 0, s, (const c32 *)iq0, (const c32 *)iq1, arena_len, desc, n, info,
+    hipLaunchKernelGGL(k_demod<1>, dim3(n), dim3(256), 0, s, (const c32 *)iq0, (const c32 *)iq1, arena_len, desc, n, info,
                        (const c32 *)chan1, (const c32 *)chan2, llr);
+    // two-stream frames only exist where a second antenna does
+    if (iq1)
+        hipLaunchKernelGGL(k_demod<2>, dim3(n), dim3(256), 0, s, (const c32 *)iq0, (const c32 *)iq1, arena_len, desc, n,
+                           info, (const c32 *)chan1, (const c32 *)chan2, llr);
 }
 void launch_viterbi(const float *llr, const gr80211_frame_info *info, const int32_t *slot_frame,
                     const GroupInfo *groups, int n_groups, uint32_t *dec, hipStream_t s)
