@@ -54,13 +54,19 @@ __device__ __forceinline__ float cabs_ref(float x, float y)
 
 // -----------------------------------------------------------------------------------------
 // k_det_ac: bit n of `mask` = ( |sum_{k<48} x[n-k-16] conj(x[n-k])| / sum_{k<64} |x[n-k]|^2 > 0.3 ).
-// One wave walks AC_ROWS rows of 64 consecutive samples, lane = sample (one coalesced 512-byte load per row, the
-// next row in flight while this one is worked on).  The window sums come from inclusive scans across the lanes
-// (six DPP adds each) of this row and the previous one: sum over the last 64 samples = S[l] + (T' - S'[l]),
-// over the last 48 = S[l] - S[l-48] or S[l] + (T' - S'[l+16]).  No sum is longer than 64 terms, so nothing
-// drifts the way the reference's running sums do.  Reads 8 B per sample once, writes 1 bit per sample.
+// One wave walks AC_ROWS rows of 256 consecutive samples, four per lane (coalesced 16-byte loads, the next row in
+// flight while this one is worked on).  A lane sums its four lag products and powers in order, the lane totals
+// are scanned across the wave (six DPP adds per quantity: a quarter of what one sample per lane would need, and
+// the DPP adds are what the kernel is priced by), and every sample's prefix sum of the row goes to a two-row ring
+// in LDS.  The window sums are differences of prefix sums: over the last 48 samples P[i] - P[i-48] (12 lanes back),
+// over the last 64 P[i] - P[i-64] (16 lanes back), reaching into the previous row through its total.  No sum is
+// longer than 256 terms, so nothing drifts the way the reference's running sums do.  Reads 8 B per sample from
+// HBM once (x[n-16] is read again, from cache), writes 1 bit per sample.
 // -----------------------------------------------------------------------------------------
-constexpr int AC_ROWS = 64;
+constexpr int AC_SPL = 4;             // samples per lane
+constexpr int AC_ROW = 64 * AC_SPL;   // samples per row
+constexpr int AC_ROWS = 16;           // rows per wave
+constexpr int AC_WAVES = 4;           // waves per workgroup
 
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ float scan_step(float v)
@@ -87,7 +93,8 @@ struct row_sums {
     float tr, ti, tp;  // row totals
 };
 
-// scans of the row whose samples are xc, given the previous row's samples xq (for x[n-16] of the first 16 lanes)
+// scans of the 64-sample row whose samples are xc, given the previous row's samples xq (for x[n-16] of the first
+// 16 lanes); used where single plateaus are looked at again (k_det_sync)
 __device__ __forceinline__ row_sums scan_row(c32d xc, c32d xq, int lane)
 {
     const int src = (lane + 48) & 63;  // lane - 16, wrapping into the previous row
@@ -110,42 +117,150 @@ __device__ __forceinline__ row_sums scan_row(c32d xc, c32d xq, int lane)
     return r;
 }
 
-__global__ __launch_bounds__(256) void k_det_ac(const c32d *__restrict__ x, long long n, uint32_t *__restrict__ mask)
+struct quad {
+    c32d v[AC_SPL];
+};
+
+// Samples [i, i + 4), i a multiple of 4.  INSIDE: the whole quad lies in the capture and the capture starts on a
+// 16-byte boundary, so it travels as two 16-byte loads that nothing guards (a wave in the middle of the capture
+// then issues the same memory instructions for every row, and the wait for a prefetched row can leave younger
+// loads in flight).  Otherwise sample by sample; outside the capture samples read as zero.
+template <bool INSIDE>
+__device__ __forceinline__ quad ld4(const c32d *x, long long i, long long n)
 {
+    quad q;
+    if (INSIDE) {
+        const float4 a = *reinterpret_cast<const float4 *>(x + i);
+        const float4 b = *reinterpret_cast<const float4 *>(x + i + 2);
+        q.v[0].x = a.x; q.v[0].y = a.y; q.v[1].x = a.z; q.v[1].y = a.w;
+        q.v[2].x = b.x; q.v[2].y = b.y; q.v[3].x = b.z; q.v[3].y = b.w;
+    } else {
+#pragma unroll
+        for (int j = 0; j < AC_SPL; j++) q.v[j] = ld(x, i + j, n);
+    }
+    return q;
+}
+
+__device__ __forceinline__ float lane63(float v)
+{
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+// prefix sums of one row into ring[par]; the row totals come back
+__device__ __forceinline__ void put_row(float (*ring)[3][AC_ROW], const quad &xc, const quad &xa, int par, int lane,
+                                        float &tr, float &ti, float &tp)
+{
+    float mr[AC_SPL], mi[AC_SPL], pw[AC_SPL];
+#pragma unroll
+    for (int j = 0; j < AC_SPL; j++) {
+        const c32d a = xa.v[j], c = xc.v[j];
+        mr[j] = a.x * c.x + a.y * c.y;  // multiply_conjugate_cc: x[n-16] * conj(x[n])
+        mi[j] = a.y * c.x - a.x * c.y;
+        pw[j] = c.x * c.x + c.y * c.y;
+    }
+#pragma unroll
+    for (int j = 1; j < AC_SPL; j++) {
+        mr[j] += mr[j - 1];
+        mi[j] += mi[j - 1];
+        pw[j] += pw[j - 1];
+    }
+    const float sr = wave_scan(mr[AC_SPL - 1]), si = wave_scan(mi[AC_SPL - 1]), sp = wave_scan(pw[AC_SPL - 1]);
+    const float er = sr - mr[AC_SPL - 1], ei = si - mi[AC_SPL - 1], ep = sp - pw[AC_SPL - 1];  // lanes before this one
+    float4 vr, vi, vp;
+    vr.x = er + mr[0]; vr.y = er + mr[1]; vr.z = er + mr[2]; vr.w = er + mr[3];
+    vi.x = ei + mi[0]; vi.y = ei + mi[1]; vi.z = ei + mi[2]; vi.w = ei + mi[3];
+    vp.x = ep + pw[0]; vp.y = ep + pw[1]; vp.z = ep + pw[2]; vp.w = ep + pw[3];
+    *reinterpret_cast<float4 *>(&ring[par][0][lane * AC_SPL]) = vr;
+    *reinterpret_cast<float4 *>(&ring[par][1][lane * AC_SPL]) = vi;
+    *reinterpret_cast<float4 *>(&ring[par][2][lane * AC_SPL]) = vp;
+    tr = lane63(vr.w);
+    ti = lane63(vi.w);
+    tp = lane63(vp.w);
+}
+
+// The rows of one wave; their mask words are left in words[] (8 per row).
+template <bool INSIDE>
+__device__ __forceinline__ void ac_rows(const c32d *__restrict__ x, long long n, long long base, int lane,
+                                        float (*ring)[3][AC_ROW], uint32_t *words)
+{
+    // the row before this wave's first one seeds the window sums
+    float ptr_, pti_, ptp_;
+    {
+        const quad xp = ld4<INSIDE>(x, base - AC_ROW + lane * AC_SPL, n);
+        const quad xq = ld4<INSIDE>(x, base - AC_ROW + lane * AC_SPL - 16, n);
+        put_row(ring, xp, xq, 1, lane, ptr_, pti_, ptp_);
+    }
+    quad xn = ld4<INSIDE>(x, base + lane * AC_SPL, n);
+    quad an = ld4<INSIDE>(x, base + lane * AC_SPL - 16, n);
+    for (int r = 0; r < AC_ROWS; r++) {
+        const long long n0 = base + (long long)r * AC_ROW;
+        if (!INSIDE && n0 >= n) break;
+        const int par = r & 1;
+        const quad xc = xn, xa = an;
+        // the next row travels while this one is worked on (INSIDE: the row after the wave's last one exists too)
+        xn = ld4<INSIDE>(x, n0 + AC_ROW + lane * AC_SPL, n);
+        an = ld4<INSIDE>(x, n0 + AC_ROW + lane * AC_SPL - 16, n);
+        float tr, ti, tp;
+        __builtin_amdgcn_wave_barrier();
+        put_row(ring, xc, xa, par, lane, tr, ti, tp);
+        __builtin_amdgcn_wave_barrier();
+        // prefix sums 48 and 64 samples back: 12 and 16 lanes back, in the previous row for the first lanes
+        const bool in48 = lane >= 12, in64 = lane >= 16;
+        const float4 cr = *reinterpret_cast<const float4 *>(&ring[par][0][lane * AC_SPL]);
+        const float4 ci = *reinterpret_cast<const float4 *>(&ring[par][1][lane * AC_SPL]);
+        const float4 cp = *reinterpret_cast<const float4 *>(&ring[par][2][lane * AC_SPL]);
+        const float4 br = *reinterpret_cast<const float4 *>(&ring[in48 ? par : par ^ 1][0][((lane + 52) & 63) * AC_SPL]);
+        const float4 bi = *reinterpret_cast<const float4 *>(&ring[in48 ? par : par ^ 1][1][((lane + 52) & 63) * AC_SPL]);
+        const float4 bp = *reinterpret_cast<const float4 *>(&ring[in64 ? par : par ^ 1][2][((lane + 48) & 63) * AC_SPL]);
+        const float cra[4] = {cr.x, cr.y, cr.z, cr.w}, cia[4] = {ci.x, ci.y, ci.z, ci.w}, cpa[4] = {cp.x, cp.y, cp.z, cp.w};
+        const float bra[4] = {br.x, br.y, br.z, br.w}, bia[4] = {bi.x, bi.y, bi.z, bi.w}, bpa[4] = {bp.x, bp.y, bp.z, bp.w};
+        uint32_t nib = 0;
+#pragma unroll
+        for (int j = 0; j < AC_SPL; j++) {
+            const float wr = in48 ? cra[j] - bra[j] : cra[j] + (ptr_ - bra[j]);
+            const float wi = in48 ? cia[j] - bia[j] : cia[j] + (pti_ - bia[j]);
+            const float wp = in64 ? cpa[j] - bpa[j] : cpa[j] + (ptp_ - bpa[j]);
+            // complex_to_mag, divide, "> 0.3" with the square root and the division taken out: |w|^2 > (0.3 wp)^2.
+            // wp is a sum of squares (never negative); where it is zero so is the lag sum and the bit stays clear,
+            // as 0/0 compares false.
+            const float lim = PLATEAU_AC * wp;
+            if ((INSIDE || n0 + lane * AC_SPL + j < n) && wr * wr + wi * wi > lim * lim) nib |= 1u << j;
+        }
+        // eight lanes make one mask word: OR the nibbles together inside each group of eight lanes
+        uint32_t w = nib << (4 * (lane & 7));
+        w |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w, 0xb1, 0xf, 0xf, false);   // quad_perm [1,0,3,2]
+        w |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w, 0x4e, 0xf, 0xf, false);   // quad_perm [2,3,0,1]
+        w |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w, 0x104, 0xf, 0xf, false);  // row_shl:4 (lane l takes l + 4)
+        if ((lane & 7) == 0) words[r * 8 + (lane >> 3)] = w;
+        ptr_ = tr;
+        pti_ = ti;
+        ptp_ = tp;
+    }
+}
+
+__global__ __launch_bounds__(64 * AC_WAVES) void k_det_ac(const c32d *__restrict__ x, long long n, uint32_t *__restrict__ mask,
+                                                         int wide)
+{
+    // per wave: two rows x (re, im, power) x 256 prefix sums, and the wave's mask words until it is done
+    __shared__ __attribute__((aligned(16))) float s_ring[AC_WAVES][2][3][AC_ROW];
+    __shared__ uint32_t s_words[AC_WAVES][AC_ROWS * 8];
     const int lane = threadIdx.x & 63;
-    const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const long long base = wave * (long long)(AC_ROWS * 64);
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long long wave = (long long)blockIdx.x * AC_WAVES + wv;
+    const long long base = wave * (long long)(AC_ROWS * AC_ROW);
     if (base >= n) return;
     const long long nwords = (n + 31) >> 5;
-    // the row before this wave's first one seeds the window sums
-    c32d xq = ld(x, base - 128 + lane, n);
-    c32d xp = ld(x, base - 64 + lane, n);
-    row_sums prev = scan_row(xp, xq, lane);
-    c32d xn = ld(x, base + lane, n);
-    for (int r = 0; r < AC_ROWS; r++) {
-        const long long n0 = base + (long long)r * 64;
-        if (n0 >= n) break;
-        const c32d xc = xn;
-        xn = ld(x, n0 + 64 + lane, n);
-        const row_sums cur = scan_row(xc, xp, lane);
-        // 48-sample window of the lag product
-        const int s48 = (lane + 16) & 63;  // lane - 48, wrapping
-        const float cr48 = __shfl(cur.sr, s48), ci48 = __shfl(cur.si, s48);
-        const float pr48 = __shfl(prev.sr, s48), pi48 = __shfl(prev.si, s48);
-        const float wr = lane >= 48 ? cur.sr - cr48 : cur.sr + (prev.tr - pr48);
-        const float wi = lane >= 48 ? cur.si - ci48 : cur.si + (prev.ti - pi48);
-        // 64-sample window of the power
-        const float wp = cur.sp + (prev.tp - prev.sp);
-        const float ac = sqrtf(wr * wr + wi * wi) / wp;  // complex_to_mag, divide
-        const unsigned long long bits = __ballot(n0 + lane < n && ac > PLATEAU_AC);
-        if (lane == 0) {
-            const long long w = n0 >> 5;
-            if (w < nwords) mask[w] = (uint32_t)bits;
-            if (w + 1 < nwords) mask[w + 1] = (uint32_t)(bits >> 32);
-        }
-        xp = xc;
-        prev = cur;
-    }
+    uint32_t *words = s_words[wv];
+    for (int k = lane; k < AC_ROWS * 8; k += 64) words[k] = 0;
+    __builtin_amdgcn_wave_barrier();
+    // a wave whose rows, the row before them and the row after them lie inside the capture needs no guards
+    const bool inside = wide && base >= AC_ROW + 16 && base + (long long)(AC_ROWS + 1) * AC_ROW <= n;
+    if (inside) ac_rows<true>(x, n, base, lane, s_ring[wv], words);
+    else ac_rows<false>(x, n, base, lane, s_ring[wv], words);
+    __builtin_amdgcn_wave_barrier();
+    const long long w0 = base >> 5;
+    for (int k = lane; k < AC_ROWS * 8; k += 64)
+        if (w0 + k < nwords) mask[w0 + k] = words[k];
 }
 
 // -----------------------------------------------------------------------------------------
@@ -644,8 +759,9 @@ int det_edge_blocks(long long n) { return (int)((det_mask_words(n) + EDGE_WORDS)
 
 void launch_det_ac(const void *iq, long long n, uint32_t *mask, hipStream_t s)
 {
-    const long long waves = (n + AC_ROWS * 64 - 1) / (AC_ROWS * 64);
-    hipLaunchKernelGGL(k_det_ac, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, (const c32d *)iq, n, mask);
+    const long long waves = (n + AC_ROWS * AC_ROW - 1) / (AC_ROWS * AC_ROW);
+    hipLaunchKernelGGL(k_det_ac, dim3((unsigned)((waves + AC_WAVES - 1) / AC_WAVES)), dim3(64 * AC_WAVES), 0, s, (const c32d *)iq, n, mask,
+                       ((uintptr_t)iq & 15) == 0 ? 1 : 0);
 }
 
 void launch_det_edge_count(const uint32_t *mask, long long n, uint32_t *blk_rise, uint32_t *blk_fall, uint32_t *totals,

@@ -72,6 +72,23 @@ def test_back_to_back_frames_and_tile_borders(pkg, rxctx, oracle):
         assert len(ref["pos"]) >= 5
 
 
+def test_capture_not_on_a_16_byte_boundary(pkg, rxctx, oracle):
+    """The capture pointer may sit on any sample (8-byte) boundary: the scan then loads sample by sample and finds
+    the same sync bytes as on an aligned copy."""
+    import torch
+    parts = [f["iq"][0].astype(np.complex64) for f in golden_frames() if f["nss"] == 1][:5]
+    x = noisy(np.concatenate(parts + [np.zeros(333, np.complex64)]), 0.004, 11)
+    ref, want = check(pkg, rxctx, oracle, x)
+    buf = torch.zeros(len(x) + 1, dtype=torch.complex64, device="cuda")
+    view = buf[1:]
+    view.copy_(torch.from_numpy(x))
+    assert view.data_ptr() % 16 == 8
+    d, n = rxctx.detect(view)
+    rxctx.sync()
+    got = d.cpu().numpy()[: n * 32].view(pkg.rx.FRAME_DESC_DTYPE)
+    assert got.tobytes() == want.tobytes()
+
+
 def test_nothing_to_find(pkg, rxctx, oracle):
     rng = np.random.default_rng(1)
     for x in (np.zeros(5000, np.complex64),
