@@ -1329,7 +1329,9 @@ __device__ __forceinline__ void viterbi_group(const float *__restrict__ llr, uns
             __builtin_amdgcn_s_setprio(2);
         else
             __builtin_amdgcn_s_setprio(0);
-        __syncthreads();
+        // the tile belongs to this wave alone: its reads of the previous chunk have returned (their values were
+        // used), so the loads below may overwrite it
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         const int c0 = ch * CH + lane;
         // 64 rows (frames) x 64 columns, transposed through LDS.  Each row is one LDS-DMA load
         // (global_load_lds_dword: lane l of the wave writes tile[row][l]), so all 64 are in flight
@@ -1348,7 +1350,7 @@ __device__ __forceinline__ void viterbi_group(const float *__restrict__ llr, uns
                                              (__attribute__((address_space(3))) void *)(tile + r * TILE_STRIDE), 4, 0, 0);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();
         uint32_t *dp = dec + (size_t)ch * STEPS * 128 + lane * 4;
 #pragma unroll 1
         for (int pp = 0; pp < NPER; pp += 2)
@@ -1648,7 +1650,12 @@ int read_timeline(unsigned long long *dst, int n_groups)
 }
 #endif
 
-__global__ __launch_bounds__(64) void k_decode(const float *__restrict__ llr, const gr80211_frame_info *__restrict__ info,
+// Four groups per workgroup, one per wave: the hardware spreads the waves of a workgroup over the four SIMDs of a
+// CU, so a CU holds either one wave per SIMD or two, never two on one SIMD beside an idle one.  The waves share
+// nothing and never meet at a barrier (their trellises differ in length).
+constexpr int DEC_WAVES = 4;
+
+__global__ __launch_bounds__(64 * DEC_WAVES) void k_decode(const float *__restrict__ llr, const gr80211_frame_info *__restrict__ info,
                                                const int32_t *__restrict__ slot_frame,
                                                const GroupInfo *__restrict__ groups, int n_groups,
                                                uint32_t *__restrict__ dec, uint32_t *__restrict__ bitsw,
@@ -1656,16 +1663,18 @@ __global__ __launch_bounds__(64) void k_decode(const float *__restrict__ llr, co
                                                int32_t *__restrict__ n_pdu, uint8_t *__restrict__ bits_out, int bits_stride,
                                                int strict)
 {
-    const int g = blockIdx.x;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = blockIdx.x * DEC_WAVES + wv;
     if (g >= n_groups) return;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
 #ifdef GR80211_TIMELINE
     if (lane == 0 && g < 8192) {
         g_timeline[4 * g] = wall_clock64();
         g_timeline[4 * g + 3] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));  // HW_ID
     }
 #endif
-    __shared__ float tile[64 * TILE_STRIDE];
+    __shared__ float tiles[DEC_WAVES][64 * TILE_STRIDE];
+    float *tile = tiles[wv];
     const GroupInfo gi = groups[g];
     const int fr = slot_frame[g * 64 + lane];
     const int myn = fr >= 0 ? info[fr].total : 0;
@@ -1683,10 +1692,10 @@ __global__ __launch_bounds__(64) void k_decode(const float *__restrict__ llr, co
 #ifdef GR80211_TIMELINE
     if (lane == 0 && g < 8192) g_timeline[4 * g + 1] = wall_clock64();
 #endif
-    __syncthreads();
-    uint32_t *s_crc = reinterpret_cast<uint32_t *>(tile);  // the LLR tile is dead from here on
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    uint32_t *s_crc = reinterpret_cast<uint32_t *>(tile);  // the wave's LLR tile is dead from here on
     for (int i = lane; i < 256; i += 64) s_crc[i] = c_tab.crc[i];
-    __syncthreads();
+    __builtin_amdgcn_wave_barrier();
     traceback_group(dec, info, gi, fr, lane, s_crc, bitsw, out, out_stride, out_len, n_pdu, bits_out, bits_stride, strict);
 #ifdef GR80211_TIMELINE
     if (lane == 0 && g < 8192) g_timeline[4 * g + 2] = wall_clock64();
@@ -1798,8 +1807,13 @@ void launch_decode(const float *llr, const gr80211_frame_info *info, const int32
                    const GroupInfo *groups, int n_groups, uint32_t *dec, uint32_t *bitsw, uint8_t *out, int out_stride,
                    int32_t *out_len, int32_t *n_pdu, uint8_t *bits_out, int bits_stride, int strict, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_decode, dim3(n_groups), dim3(64), 0, s, llr, info, slot_frame, groups, n_groups, dec, bitsw,
-                       out, out_stride, out_len, n_pdu, bits_out, bits_stride, strict);
+    // A batch of at most one group per SIMD runs fastest with exactly one wave on every SIMD (a lone wave finishes
+    // its trellis in two thirds of the time a paired one needs).  The kernel's own 65 KB of LDS let two workgroups
+    // share a CU; unused LDS on top of that leaves room for one, so that 256 workgroups cover the 256 CUs.
+    const size_t spread = n_groups <= 1024 ? 16 * 1024 : 0;
+    hipLaunchKernelGGL(k_decode, dim3((n_groups + DEC_WAVES - 1) / DEC_WAVES), dim3(64 * DEC_WAVES), spread, s, llr, info,
+                       slot_frame, groups, n_groups, dec, bitsw, out, out_stride, out_len, n_pdu, bits_out, bits_stride,
+                       strict);
 }
 void launch_ndp_emit(const void *iq0, uint64_t arena_len, const gr80211_frame_desc *desc, int n,
                      const gr80211_frame_info *info, uint8_t *out, int out_stride, int32_t *out_len, int32_t *n_pdu,
