@@ -1305,17 +1305,41 @@ __device__ __forceinline__ void two_periods(float (&A)[64], float (&B)[64], cons
 }
 
 
-template <int CR>
+// 64 rows (frames) x 64 columns of soft bits, transposed through LDS.  Each row is one LDS-DMA load
+// (global_load_lds_dword: lane l of the wave writes tile[row][l]), so all 64 are in flight together and cost no
+// VGPRs while the 128 path-metric registers are live.  Columns past a frame's last soft bit are clamped to it:
+// they only feed trellis steps after that frame's end.
+__device__ __forceinline__ void load_tile(const float *__restrict__ llr, unsigned long long mybase, int myn, int c0,
+                                          float *tile)
+{
+#pragma unroll
+    for (int r = 0; r < 64; r++) {
+        const unsigned lo = __builtin_amdgcn_readlane((int)(mybase & 0xffffffffull), r);
+        const unsigned hi = __builtin_amdgcn_readlane((int)(mybase >> 32), r);
+        const int nr = __builtin_amdgcn_readlane(myn, r);
+        const unsigned long long base = ((unsigned long long)hi << 32) | lo;
+        int idx = c0 < nr ? c0 : nr - 1;
+        idx = idx < 0 ? 0 : idx;
+        const float *src = llr + base + (unsigned long long)idx;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                         (__attribute__((address_space(3))) void *)(tile + r * TILE_STRIDE), 4, 0, 0);
+    }
+}
+
+// Forward pass of one group.  TWO_TILES: the wave has room for two tiles in LDS (a batch of at most one group per
+// SIMD) and fetches the next chunk's soft bits while it works on this one; a wave that shares its SIMD leaves the
+// fetch latency to its partner instead.
+template <int CR, bool TWO_TILES>
 __device__ __forceinline__ void viterbi_group(const float *__restrict__ llr, unsigned long long mybase, int myn,
                                               int nchunks, uint32_t *__restrict__ dec, float *tile, int lane)
 {
     constexpr int P = Rate<CR>::P, COLS = Rate<CR>::COLS, NPER = Rate<CR>::NPER;
     constexpr int CH = COLS * NPER;    // LLR columns per tile
     constexpr int STEPS = P * NPER;    // trellis steps per tile
+    static_assert(STEPS / 2 < 63, "the wait below counts one survivor store per step pair");
     float A[64], B[64];
 #pragma unroll
     for (int i = 0; i < 64; i++) A[i] = i == 0 ? 0.0f : NEG_INIT;
-    const float *row = tile + lane * TILE_STRIDE;
 #ifndef GR80211_PRIO_SHIFT
 #define GR80211_PRIO_SHIFT 13
 #endif
@@ -1324,33 +1348,31 @@ __device__ __forceinline__ void viterbi_group(const float *__restrict__ llr, uns
     // waves therefore trade priority in time slices of 2^GR80211_PRIO_SHIFT ticks of the 100-MHz clock (both
     // read the same clock; the wave slot number tells them apart), so that both stay paired until the end.
     const unsigned slot_parity = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (3 << 11)) & 1u;  // HW_ID.wave_id
+    if (TWO_TILES) load_tile(llr, mybase, myn, lane, tile);
     for (int ch = 0; ch < nchunks; ch++) {
-        if ((((unsigned)(__builtin_amdgcn_s_memrealtime() >> GR80211_PRIO_SHIFT)) ^ slot_parity) & 1u)
-            __builtin_amdgcn_s_setprio(2);
-        else
-            __builtin_amdgcn_s_setprio(0);
-        // the tile belongs to this wave alone: its reads of the previous chunk have returned (their values were
-        // used), so the loads below may overwrite it
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        const int c0 = ch * CH + lane;
-        // 64 rows (frames) x 64 columns, transposed through LDS.  Each row is one LDS-DMA load
-        // (global_load_lds_dword: lane l of the wave writes tile[row][l]), so all 64 are in flight
-        // together and cost no VGPRs while the 128 path-metric registers are live.  Columns past a
-        // frame's last soft bit are clamped to it: they only feed trellis steps after that frame's end.
-#pragma unroll
-        for (int r = 0; r < 64; r++) {
-            const unsigned lo = __builtin_amdgcn_readlane((int)(mybase & 0xffffffffull), r);
-            const unsigned hi = __builtin_amdgcn_readlane((int)(mybase >> 32), r);
-            const int nr = __builtin_amdgcn_readlane(myn, r);
-            const unsigned long long base = ((unsigned long long)hi << 32) | lo;
-            int idx = c0 < nr ? c0 : nr - 1;
-            idx = idx < 0 ? 0 : idx;
-            const float *src = llr + base + (unsigned long long)idx;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                             (__attribute__((address_space(3))) void *)(tile + r * TILE_STRIDE), 4, 0, 0);
+        float *cur = tile;
+        if (TWO_TILES) {
+            cur = tile + (ch & 1) * (64 * TILE_STRIDE);
+            // this chunk's soft bits were requested a chunk ago; the only younger memory operations are the
+            // survivor stores of the chunk in between (none before the first chunk), which may stay in flight
+            if (ch == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(STEPS / 2) : "memory");
+            // the other tile's last readers were the steps of the previous chunk: their values have arrived
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (ch + 1 < nchunks) load_tile(llr, mybase, myn, (ch + 1) * CH + lane, tile + ((ch + 1) & 1) * (64 * TILE_STRIDE));
+        } else {
+            if ((((unsigned)(__builtin_amdgcn_s_memrealtime() >> GR80211_PRIO_SHIFT)) ^ slot_parity) & 1u)
+                __builtin_amdgcn_s_setprio(2);
+            else
+                __builtin_amdgcn_s_setprio(0);
+            // the tile belongs to this wave alone: its reads of the previous chunk have returned (their values were
+            // used), so the loads below may overwrite it
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            load_tile(llr, mybase, myn, ch * CH + lane, tile);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
+        const float *row = cur + lane * TILE_STRIDE;
         uint32_t *dp = dec + (size_t)ch * STEPS * 128 + lane * 4;
 #pragma unroll 1
         for (int pp = 0; pp < NPER; pp += 2)
@@ -1374,10 +1396,10 @@ __global__ __launch_bounds__(64) void k_viterbi(const float *__restrict__ llr, c
     const unsigned long long mybase = myn > 0 ? (unsigned long long)info[fr].llr_off : 0ull;
     uint32_t *d = dec + gi.dec_off;
     switch (gi.cr) {
-    case CR_12: viterbi_group<CR_12>(llr, mybase, myn, gi.nchunks, d, tile, lane); break;
-    case CR_23: viterbi_group<CR_23>(llr, mybase, myn, gi.nchunks, d, tile, lane); break;
-    case CR_34: viterbi_group<CR_34>(llr, mybase, myn, gi.nchunks, d, tile, lane); break;
-    default: viterbi_group<CR_56>(llr, mybase, myn, gi.nchunks, d, tile, lane); break;
+    case CR_12: viterbi_group<CR_12, false>(llr, mybase, myn, gi.nchunks, d, tile, lane); break;
+    case CR_23: viterbi_group<CR_23, false>(llr, mybase, myn, gi.nchunks, d, tile, lane); break;
+    case CR_34: viterbi_group<CR_34, false>(llr, mybase, myn, gi.nchunks, d, tile, lane); break;
+    default: viterbi_group<CR_56, false>(llr, mybase, myn, gi.nchunks, d, tile, lane); break;
     }
 }
 
@@ -1655,6 +1677,7 @@ int read_timeline(unsigned long long *dst, int n_groups)
 // nothing and never meet at a barrier (their trellises differ in length).
 constexpr int DEC_WAVES = 4;
 
+template <bool TWO_TILES>
 __global__ __launch_bounds__(64 * DEC_WAVES) void k_decode(const float *__restrict__ llr, const gr80211_frame_info *__restrict__ info,
                                                const int32_t *__restrict__ slot_frame,
                                                const GroupInfo *__restrict__ groups, int n_groups,
@@ -1673,7 +1696,7 @@ __global__ __launch_bounds__(64 * DEC_WAVES) void k_decode(const float *__restri
         g_timeline[4 * g + 3] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));  // HW_ID
     }
 #endif
-    __shared__ float tiles[DEC_WAVES][64 * TILE_STRIDE];
+    __shared__ float tiles[DEC_WAVES][(TWO_TILES ? 2 : 1) * 64 * TILE_STRIDE];
     float *tile = tiles[wv];
     const GroupInfo gi = groups[g];
     const int fr = slot_frame[g * 64 + lane];
@@ -1681,10 +1704,10 @@ __global__ __launch_bounds__(64 * DEC_WAVES) void k_decode(const float *__restri
     const unsigned long long mybase = myn > 0 ? (unsigned long long)info[fr].llr_off : 0ull;
     uint32_t *d = dec + gi.dec_off;
     switch (gi.cr) {
-    case CR_12: viterbi_group<CR_12>(llr, mybase, myn, gi.nchunks, d, tile, lane); break;
-    case CR_23: viterbi_group<CR_23>(llr, mybase, myn, gi.nchunks, d, tile, lane); break;
-    case CR_34: viterbi_group<CR_34>(llr, mybase, myn, gi.nchunks, d, tile, lane); break;
-    default: viterbi_group<CR_56>(llr, mybase, myn, gi.nchunks, d, tile, lane); break;
+    case CR_12: viterbi_group<CR_12, TWO_TILES>(llr, mybase, myn, gi.nchunks, d, tile, lane); break;
+    case CR_23: viterbi_group<CR_23, TWO_TILES>(llr, mybase, myn, gi.nchunks, d, tile, lane); break;
+    case CR_34: viterbi_group<CR_34, TWO_TILES>(llr, mybase, myn, gi.nchunks, d, tile, lane); break;
+    default: viterbi_group<CR_56, TWO_TILES>(llr, mybase, myn, gi.nchunks, d, tile, lane); break;
     }
     // every lane reads back only survivor words it stored itself; drain the stores first
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1807,13 +1830,17 @@ void launch_decode(const float *llr, const gr80211_frame_info *info, const int32
                    const GroupInfo *groups, int n_groups, uint32_t *dec, uint32_t *bitsw, uint8_t *out, int out_stride,
                    int32_t *out_len, int32_t *n_pdu, uint8_t *bits_out, int bits_stride, int strict, hipStream_t s)
 {
+    const dim3 grid((n_groups + DEC_WAVES - 1) / DEC_WAVES), block(64 * DEC_WAVES);
     // A batch of at most one group per SIMD runs fastest with exactly one wave on every SIMD (a lone wave finishes
-    // its trellis in two thirds of the time a paired one needs).  The kernel's own 65 KB of LDS let two workgroups
-    // share a CU; unused LDS on top of that leaves room for one, so that 256 workgroups cover the 256 CUs.
-    const size_t spread = n_groups <= 1024 ? 16 * 1024 : 0;
-    hipLaunchKernelGGL(k_decode, dim3((n_groups + DEC_WAVES - 1) / DEC_WAVES), dim3(64 * DEC_WAVES), spread, s, llr, info,
-                       slot_frame, groups, n_groups, dec, bitsw, out, out_stride, out_len, n_pdu, bits_out, bits_stride,
-                       strict);
+    // its trellis in three quarters of the time a paired one needs).  The two-tile form needs 130 KB of LDS per
+    // workgroup, so a CU takes one workgroup and 256 workgroups cover the 256 CUs; the one-tile form (65 KB) lets two
+    // workgroups share a CU, two waves per SIMD.
+    if (n_groups <= 1024)
+        hipLaunchKernelGGL(k_decode<true>, grid, block, 0, s, llr, info, slot_frame, groups, n_groups, dec, bitsw, out,
+                           out_stride, out_len, n_pdu, bits_out, bits_stride, strict);
+    else
+        hipLaunchKernelGGL(k_decode<false>, grid, block, 0, s, llr, info, slot_frame, groups, n_groups, dec, bitsw, out,
+                           out_stride, out_len, n_pdu, bits_out, bits_stride, strict);
 }
 void launch_ndp_emit(const void *iq0, uint64_t arena_len, const gr80211_frame_desc *desc, int n,
                      const gr80211_frame_info *info, uint8_t *out, int out_stride, int32_t *out_len, int32_t *n_pdu,
