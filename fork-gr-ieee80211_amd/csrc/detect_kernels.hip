@@ -612,8 +612,9 @@ __global__ __launch_bounds__(64) void k_det_sync(const c32d *__restrict__ x, lon
     const float step_stf = atan2f(cvi, cvr) / 16.0f;
     {
         const c32d a = s_x[m + lane], b = s_x[m + lane + 64];
-        const float ca = cosf(lane * step_stf), sa = sinf(lane * step_stf);
-        const float cb = cosf((lane + 64) * step_stf), sb = sinf((lane + 64) * step_stf);
+        float ca, sa, cb, sb;
+        sincosf(lane * step_stf, &sa, &ca);
+        sincosf((lane + 64) * step_stf, &sb, &cb);
         const float ar = a.x * ca - a.y * sa, ai = a.x * sa + a.y * ca;
         const float br = b.x * cb - b.y * sb, bi = b.x * sb + b.y * cb;
         c32d p;
