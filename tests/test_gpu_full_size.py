@@ -57,11 +57,12 @@ def test_configured_batch_round_trip(pkg, rxctx, oracle, workload, n_oracle):
         assert got == ref["blob"], (workload, int(i))
 
 
-@pytest.mark.parametrize("two_ant,n_frames", [(False, 125000), (True, 20000)])
+@pytest.mark.parametrize("two_ant,n_frames", [(False, 125000), (False, 52000), (True, 20000)])
 def test_mixed_capture_corpus_replicated(pkg, rxctx, oracle, two_ant, n_frames):
     """Mixed L/HT/VHT corpus (the reference's IQ fixtures + the Python-reference frames) replicated round-robin
     to a full shard: every replica must give exactly what the oracle gives for its source frame.  Exercises the
-    group scheduler with many (code rate, length) classes and partly filled groups."""
+    group scheduler with many (code rate, length) classes and partly filled groups, in the three regimes of the
+    decoder (more groups than SIMDs, at most one group per SIMD, four waves per group)."""
     import torch
     from util import H22, golden_frames, ref_fixtures
     dev = torch.device("cuda", 0)
