@@ -189,8 +189,23 @@ def copy_ref_fixtures():
                     o.write(hexs + "\n")
 
 
+def make_txbits():
+    """The bit vectors the reference keeps in tools/txbits.py (data, scrambled, coded and interleaved bits of its
+    94-byte example packet at HT MCS0; a VHT-SIG-B field before and after coding and interleaving; VHT data bits
+    before and after scrambling), read as literals and stored as arrays."""
+    import ast
+    import re
+    src = open(os.path.join(REF_TOOLS, "txbits.py")).read()
+    out = {}
+    for m in re.finditer(r"^(\w+)\s*=\s*(\[.*?\])", src, re.S | re.M):
+        out[m.group(1)] = np.array(ast.literal_eval(m.group(2)), dtype=np.uint8)
+    assert len(out) == 11
+    np.savez_compressed(os.path.join(HERE, "ref_txbits.npz"), **out)
+
+
 if __name__ == "__main__":
     copy_ref_fixtures()
+    make_txbits()
     make_viterbi()
     make_frames()
     make_ndp()

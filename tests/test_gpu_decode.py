@@ -1,5 +1,7 @@
 """decode path on the GPU (gr80211_decode_batch) against the CPU oracle: bit-exact decoded bits,
 PDUs and FCS verdicts, for every code rate, ragged lengths, ties, erasures and edge cases."""
+import os
+
 import numpy as np
 import pytest
 
@@ -246,3 +248,34 @@ def test_group_widths_agree_bit_for_bit(pkg, ctx_by_waves):
         assert np.array_equal(np.unpackbits(got[1][3], axis=1, bitorder="little")[tb],
                               np.unpackbits(got[w][3], axis=1, bitorder="little")[tb]), w
         assert np.array_equal(got[1][0][valid], got[w][0][valid]), w
+
+
+def test_reference_bit_vector_decodes_to_reference_packet(pkg, ctx_by_waves):
+    """The interleaved coded bits the reference keeps for its example packet (tools/txbits.py, HT MCS0), put
+    through its own deinterleaver map as hard soft bits: both decoder forms must return the packet its IQ
+    fixtures carry.  No oracle in the loop: reference data in, reference data out."""
+    import torch
+    from util import GOLDEN, ref_fixture_mpdu
+    z = np.load(os.path.join(GOLDEN, "ref_txbits.npz"))
+    inter = z["htMcs0interBits"]
+    m = np.asarray(pkg.txgen.interleave_map(52, 1, 13))
+    llr = np.zeros(len(inter), np.float32)
+    for s in range(len(inter) // 52):
+        # the transmitter puts coded bit k at place m[k]; the receiver reads it back from there
+        llr[52 * s:52 * s + 52] = inter[52 * s + m].astype(np.float32) * 2 - 1
+    assert np.array_equal((llr > 0).astype(np.uint8), z["htMcs0CodedBits"])
+    n = 130   # more than a wave of copies: two groups
+    desc = np.zeros(n, dtype=pkg.rx.DEC_DESC_DTYPE)
+    for i in range(n):
+        desc[i] = (i * len(llr), len(llr), 1, 94, 0, 0, 0, 8 * 94 + 22, 0)
+    d_llr = torch.from_numpy(np.tile(llr, n)).cuda()
+    want = bytes([1, 94, 0]) + ref_fixture_mpdu() + bytes([0])
+    for waves in (1, 4):
+        c = ctx_by_waves[waves]
+        r = c.decode_batch(d_llr, desc, n)
+        c.sync()
+        lens = r["out_len"].cpu().numpy()
+        out = r["out"].cpu().numpy()
+        assert (r["n_pdu"].cpu().numpy() == 1).all()
+        for i in (0, 63, 64, 129):
+            assert bytes(out[i, : lens[i]]) == want, (waves, i)

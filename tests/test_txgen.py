@@ -51,3 +51,30 @@ def test_vht_multi_mpdu_ampdu(pkg, oracle):
     rx = np.concatenate([np.zeros(30), sig[0] * 12.0, np.zeros(30)]).astype(np.complex64)
     r = oracle.rx_frame(rx, None, 30 + 176, 0.0)
     assert [p["mpdu"] for p in r["pdus"]] == ms
+
+
+def test_reference_bit_vectors(pkg):
+    """The stages of the transmitter against the bit vectors in the reference's tools/txbits.py: scrambler (seed
+    93) with the tail zeroed afterwards, convolutional encoder, HT BPSK interleaver, and the coded and interleaved
+    VHT-SIG-B field."""
+    import os
+    tx = pkg.txgen
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_txbits.npz"))
+    data = z["htMcs0DataBits"]
+    assert np.array_equal(data, z["htMcs1DataBits"]) and np.array_equal(data, z["htMcs7DataBits"])
+    scr = data ^ np.asarray(tx.scramble_seq(len(data), 93), dtype=np.uint8)
+    scr[16 + 8 * 94:16 + 8 * 94 + 6] = 0
+    coded = np.asarray(tx.bcc_encode(scr), dtype=np.uint8)
+    assert np.array_equal(coded, z["htMcs0CodedBits"])
+    m = np.asarray(tx.interleave_map(52, 1, 13))
+    inter = np.zeros_like(coded)
+    for s in range(len(coded) // 52):
+        inter[52 * s + m] = coded[52 * s:52 * s + 52]
+    assert np.array_equal(inter, z["htMcs0interBits"])
+    sv = z["vhtDataBitsMcs0"] ^ np.asarray(tx.scramble_seq(len(z["vhtDataBitsMcs0"]), 93), dtype=np.uint8)
+    assert np.array_equal(sv, z["vhtScrameBitsMcs0"])
+    sb = np.asarray(tx.bcc_encode(z["vhtSigBmcs0"]), dtype=np.uint8)
+    assert np.array_equal(sb, z["vhtSigBmcs0Bcc"])
+    si = np.zeros(52, np.uint8)
+    si[m] = sb
+    assert np.array_equal(si, z["vhtSigBmcs0BccInter"])
