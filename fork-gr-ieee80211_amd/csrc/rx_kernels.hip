@@ -4,13 +4,15 @@
 //                L-SIG / HT-SIG / VHT-SIG-A / VHT-SIG-B soft decoding (lane = trellis state),
 //                HT/VHT channel estimate incl. the 2x2 Gram inverse.
 //   k_sched_*    bucket frames by code rate and trellis length into groups of 64 (decoder lanes).
-//   k_demod      one wavefront per OFDM symbol: FFT-64 by lane shuffles, one-tap or 2x2 ZF
-//                equalisation, pilot phase tracking, QAM soft demap, deinterleave / stream deparse
-//                folded into the store address.
-//   k_viterbi    one wavefront per group, lane = frame: 64-state add-compare-select fully in
-//                registers, depuncturing folded into the per-rate unrolled step sequence,
-//                LLRs staged (transposed) through LDS, survivor bits streamed to HBM.
-//   k_traceback  lane = frame: full-frame traceback, descrambling, (A-)MPDU assembly, FCS.
+//   k_demod<1|2> one workgroup per frame, its waves stride over the OFDM symbols: FFT-64 by lane shuffles, one-tap
+//                or 2x2 ZF equalisation, pilot phase tracking, QAM soft demap, deinterleave / stream deparse
+//                folded into the place a soft bit takes in the wave's LDS stage.
+//   k_decode     one wavefront per group (four groups per workgroup), lane = frame: 64-state add-compare-select
+//                fully in registers, depuncturing folded into the per-rate unrolled step sequence, LLRs staged
+//                (transposed) through LDS, survivor bits streamed to HBM; then the same wave walks them back:
+//                full-frame traceback, descrambling, (A-)MPDU assembly, FCS.
+//   k_viterbi / k_traceback   the two halves of k_decode as kernels of their own (k_traceback also follows the
+//                four-waves-per-group forward pass of vit_split.hip).
 //
 // Built with -ffp-contract=off: the decoder's path metrics must be the plain float32 sums the
 // reference forms (lib/decode_impl.cc:231-258), and the demodulator follows the reference's
