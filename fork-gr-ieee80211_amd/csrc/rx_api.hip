@@ -28,7 +28,7 @@ struct gr80211_ctx {
     Buf desc, ddesc, info, chan1, chan2, llr, slot_frame, groups, dec, bitsw, totals_d, sched_ws, blk_llr;
     // frame detection
     Buf det_mask, det_blk, det_runs, det_rec, det_totals_d, cap_desc, cap_ws;
-    Buf tx_desc;
+    Buf tx_desc, sig_desc, chanl, out_off;
     uint32_t *det_totals_h = nullptr;  // pinned
     SchedTotals *totals_h = nullptr;  // pinned
     int ampdu_strict = 0;  // de-aggregate A-MPDUs by the standard's rules instead of the reference's
@@ -209,7 +209,8 @@ int stage_desc(gr80211_ctx *c, hipStream_t s, const void *desc, size_t bytes, un
 }
 
 int front_end(gr80211_ctx *c, hipStream_t s, const void *d_iq0, const void *d_iq1, uint64_t arena_len,
-              const gr80211_frame_desc *desc, int n, unsigned flags, const gr80211_frame_desc **d_desc)
+              const gr80211_frame_desc *desc, int n, unsigned flags, const gr80211_frame_desc **d_desc,
+              const gr80211_sig_desc *d_sig = nullptr, const void *d_chan_in = nullptr, void *d_chanl_out = nullptr)
 {
     int rc;
     const void *dd = nullptr;
@@ -219,7 +220,7 @@ int front_end(gr80211_ctx *c, hipStream_t s, const void *d_iq0, const void *d_iq
     if (d_iq1 && (rc = ensure(c, c->chan2, (size_t)n * 520 * 8))) return rc;
     mark(c, 0, s);
     launch_preamble(d_iq0, d_iq1, arena_len, (const gr80211_frame_desc *)dd, n, (gr80211_frame_info *)c->info.p,
-                    c->chan1.p, c->chan2.p, s);
+                    c->chan1.p, c->chan2.p, d_sig, d_chan_in, d_chanl_out, s);
     mark(c, 1, s);
     *d_desc = (const gr80211_frame_desc *)dd;
     return GR80211_OK;
@@ -331,7 +332,7 @@ void gr80211_destroy(gr80211_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (Buf *b : {&c->desc, &c->ddesc, &c->info, &c->chan1, &c->chan2, &c->llr, &c->slot_frame, &c->groups, &c->dec,
                    &c->bitsw, &c->totals_d, &c->sched_ws, &c->blk_llr, &c->det_mask, &c->det_blk, &c->det_runs,
-                   &c->det_rec, &c->det_totals_d, &c->cap_desc, &c->cap_ws, &c->tx_desc})
+                   &c->det_rec, &c->det_totals_d, &c->cap_desc, &c->cap_ws, &c->tx_desc, &c->sig_desc, &c->chanl, &c->out_off})
         release(*b);
     if (c->totals_h) (void)hipHostFree(c->totals_h);
     if (c->det_totals_h) (void)hipHostFree(c->det_totals_h);
@@ -453,6 +454,65 @@ int gr80211_signal_batch(gr80211_ctx *c, const void *d_iq0, const void *d_iq1, u
     HIP_TRY(c, hipMemcpyAsync(d_info, c->info.p, (size_t)n * sizeof(gr80211_frame_info), hipMemcpyDeviceToDevice, s));
     HIP_TRY(c, hipGetLastError());
     return GR80211_OK;
+}
+
+int gr80211_signal_emit_batch(gr80211_ctx *c, const void *d_iq0, const void *d_iq1, uint64_t arena_len,
+                              const gr80211_frame_desc *desc, int n, unsigned flags, const uint64_t *out_off, void *d_out0,
+                              void *d_out1, uint64_t out_len, gr80211_frame_info *d_info, void *d_chan, void *stream)
+{
+    if (!c) return GR80211_ERR_ARG;
+    if (n == 0) return GR80211_OK;
+    if (!d_iq0 || !desc || n < 0 || !out_off || !d_out0 || (d_iq1 && !d_out1) || arena_len == 0)
+        return fail(c, GR80211_ERR_ARG, "gr80211_signal_emit_batch: bad argument");
+    if (n > (1 << 20)) return fail(c, GR80211_ERR_ARG, "gr80211_signal_emit_batch: at most 1048576 frames per call");
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = pick(c, stream);
+    int rc;
+    const void *d_off = nullptr;
+    if ((rc = stage_desc(c, s, out_off, (size_t)n * sizeof(uint64_t), flags, c->out_off, &d_off))) return rc;
+    if (!d_chan) {
+        if ((rc = ensure(c, c->chanl, (size_t)n * 64 * 8))) return rc;
+        d_chan = c->chanl.p;
+    }
+    const gr80211_frame_desc *dd = nullptr;
+    if ((rc = front_end(c, s, d_iq0, d_iq1, arena_len, desc, n, flags, &dd, nullptr, nullptr, d_chan))) return rc;
+    launch_signal_copy(d_iq0, d_iq1, arena_len, dd, n, (const gr80211_frame_info *)c->info.p, (const uint64_t *)d_off, d_out0,
+                       d_iq1 ? d_out1 : nullptr, out_len, s);
+    if (d_info)
+        HIP_TRY(c, hipMemcpyAsync(d_info, c->info.p, (size_t)n * sizeof(gr80211_frame_info), hipMemcpyDeviceToDevice, s));
+    HIP_TRY(c, hipGetLastError());
+    return GR80211_OK;
+}
+
+int gr80211_demod_tagged_batch(gr80211_ctx *c, const void *d_iq0, const void *d_iq1, uint64_t arena_len,
+                               const gr80211_sig_desc *desc, int n, unsigned flags, const void *d_chan,
+                               gr80211_frame_info *d_info, const float **d_llr, uint64_t *llr_floats, void *stream)
+{
+    if (!c) return GR80211_ERR_ARG;
+    if (!d_iq0 || !desc || n < 0 || !d_llr || !d_chan || arena_len == 0)
+        return fail(c, GR80211_ERR_ARG, "gr80211_demod_tagged_batch: bad argument");
+    if (n > (1 << 20)) return fail(c, GR80211_ERR_ARG, "gr80211_demod_tagged_batch: at most 1048576 frames per call");
+    *d_llr = nullptr;
+    if (llr_floats) *llr_floats = 0;
+    if (n == 0) return GR80211_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = pick(c, stream);
+    int rc;
+    const void *d_sig = nullptr;
+    if ((rc = stage_desc(c, s, desc, (size_t)n * sizeof(gr80211_sig_desc), flags, c->sig_desc, &d_sig))) return rc;
+    // the tags become descriptors of the kind the kernels read, marked as starting after L-SIG
+    if ((rc = ensure(c, c->desc, (size_t)n * sizeof(gr80211_frame_desc)))) return rc;
+    launch_sig_to_desc((const gr80211_sig_desc *)d_sig, n, (gr80211_frame_desc *)c->desc.p, s);
+    const gr80211_frame_desc *dd = nullptr;
+    if ((rc = front_end(c, s, d_iq0, d_iq1, arena_len, (const gr80211_frame_desc *)c->desc.p, n, GR80211_FLAG_DESC_ON_DEVICE, &dd,
+                        (const gr80211_sig_desc *)d_sig, d_chan)))
+        return rc;
+    rc = run_decode_stages(c, s, n, true, d_iq0, d_iq1, arena_len, dd, nullptr, nullptr, 0, nullptr, nullptr, nullptr, 0, false,
+                           d_llr, llr_floats);
+    if (rc) return rc;
+    if (d_info)
+        HIP_TRY(c, hipMemcpyAsync(d_info, c->info.p, (size_t)n * sizeof(gr80211_frame_info), hipMemcpyDeviceToDevice, s));
+    return finish_timing(c, s);
 }
 
 int gr80211_demod_batch(gr80211_ctx *c, const void *d_iq0, const void *d_iq1, uint64_t arena_len,

@@ -32,8 +32,13 @@ __host__ __device__ constexpr int chunk_steps(int cr) { return cr == CR_12 ? 32 
 
 int upload_tables(const Tables &t);
 
-void launch_preamble(const void *iq0, const void *iq1, uint64_t arena_len, const gr80211_frame_desc *desc,
-                     int n, gr80211_frame_info *info, void *chan1, void *chan2, hipStream_t s);
+void launch_preamble(const void *iq0, const void *iq1, uint64_t arena_len, const gr80211_frame_desc *desc, int n,
+                     gr80211_frame_info *info, void *chan1, void *chan2, const gr80211_sig_desc *sig, const void *chan_in,
+                     void *chanl_out, hipStream_t s);
+void launch_sig_to_desc(const gr80211_sig_desc *sig, int n, gr80211_frame_desc *desc, hipStream_t s);
+void launch_signal_copy(const void *iq0, const void *iq1, uint64_t arena_len, const gr80211_frame_desc *desc, int n,
+                        const gr80211_frame_info *info, const uint64_t *out_off, void *out0, void *out1, uint64_t out_len,
+                        hipStream_t s);
 void launch_desc_to_info(const gr80211_dec_desc *desc, int n, uint64_t llr_floats, gr80211_frame_info *info, hipStream_t s);
 void launch_schedule(gr80211_frame_info *info, int n, int assign_llr, int32_t *slot_frame, int slot_cap,
                      GroupInfo *groups, int group_cap, SchedTotals *totals, uint32_t *ws, unsigned long long *blk_llr,

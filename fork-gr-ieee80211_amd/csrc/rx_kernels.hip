@@ -326,10 +326,30 @@ __device__ __forceinline__ int frame_window(const gr80211_frame_desc &d, uint64_
     return (int)(navail64 > 0x7fffffffull ? 0x7fffffffull : navail64);
 }
 
+// A descriptor made from `signal`'s tags (gr80211_demod_tagged_batch) points at the first item `demod` sees: the
+// 224 samples between the trigger byte and that item (L-LTF, L-SIG) are not in the arena.
+constexpr uint32_t DESC_AFTER_SIGNAL = 1u;
+
+// Base pointers such that base[224 + k] is item k of the stream `demod` sees, for either kind of descriptor, and the
+// number of samples the frame has counted from the (real or virtual) trigger byte.  The pointers may lie before
+// the arena; nothing below base[224] is read through them unless the preamble is there.
+__device__ __forceinline__ int frame_origin(const gr80211_frame_desc &d, uint64_t arena_len, const c32 *iq0,
+                                            const c32 *iq1, const c32 **in0, const c32 **in1)
+{
+    uint64_t so;
+    const int navail = frame_window(d, arena_len, &so);
+    const int gone = (d.reserved & DESC_AFTER_SIGNAL) ? 224 : 0;
+    *in0 = iq0 + so - gone;
+    *in1 = iq1 ? iq1 + so - gone : nullptr;
+    return navail > 0x7fffffff - gone ? 0x7fffffff : navail + gone;
+}
+
 __global__ __launch_bounds__(64) void k_preamble(const c32 *__restrict__ iq0, const c32 *__restrict__ iq1,
                                                  uint64_t arena_len, const gr80211_frame_desc *__restrict__ descs,
                                                  int n, gr80211_frame_info *__restrict__ info,
-                                                 c32 *__restrict__ chan1, c32 *__restrict__ chan2)
+                                                 c32 *__restrict__ chan1, c32 *__restrict__ chan2,
+                                                 const gr80211_sig_desc *__restrict__ sig,
+                                                 const c32 *__restrict__ chan_in, c32 *__restrict__ chanl_out)
 {
     const int f = blockIdx.x;
     if (f >= n) return;
@@ -345,12 +365,11 @@ __global__ __launch_bounds__(64) void k_preamble(const c32 *__restrict__ iq0, co
     __shared__ double s_red[64];
 
     const gr80211_frame_desc d = descs[f];
-    uint64_t so;
-    const int navail = frame_window(d, arena_len, &so);
+    const c32 *in0, *in1;
+    const int navail = frame_origin(d, arena_len, iq0, iq1, &in0, &in1);
     const float rad = d.rad;
-    const c32 *in0 = iq0 + so;
-    const c32 *in1 = iq1 ? iq1 + so : nullptr;
     const bool two_ant = in1 != nullptr;
+    const bool after_signal = (d.reserved & DESC_AFTER_SIGNAL) != 0;
 
     if (lane < 8) s_ctl[lane] = 0;
     if (lane == 0) {
@@ -370,12 +389,31 @@ __global__ __launch_bounds__(64) void k_preamble(const c32 *__restrict__ iq0, co
     int nvalid = 0;
     int pos = 0;
 
-    if (navail < 224) {
+    if (navail < 224 || (after_signal && (!sig || !chan_in))) {
         if (lane == 0) s_ctl[0] = GR80211_ST_DROP_LSIG;
         __syncthreads();
         goto finish;
     }
 
+    if (after_signal) {
+        // what `signal` found travels in the tags (lib/demod_impl.cc:75-100): L-SIG rate and length, the sample
+        // count and the L-LTF channel; fields a correct `signal` cannot have sent are refused
+        const gr80211_sig_desc sd = sig[f];
+        if (lused) hl = chan_in[(size_t)f * 64 + bin];
+        if (lane == 0) {
+            const int ndbps_l[8] = {24, 36, 48, 72, 96, 144, 192, 216};
+            if (sd.mcs < 0 || sd.mcs > 7 || sd.len < 1 || sd.len > 4095 ||
+                sd.nsamp != ((sd.len * 8 + 22 + ndbps_l[sd.mcs & 7] - 1) / ndbps_l[sd.mcs & 7]) * 80) {
+                s_ctl[0] = GR80211_ST_DROP_LSIG;
+            } else {
+                s_ctl[1] = sd.mcs;
+                s_ctl[2] = sd.len;
+                s_ctl[3] = sd.nsamp;
+            }
+        }
+        __syncthreads();
+        if (s_ctl[0] != GR80211_ST_OK) goto finish;
+    } else
     // ---- signal: L-LTF x2 + L-SIG (lib/signal_impl.cc:108-162, lib/cloud80211phy.cc:609-627)
     {
         c32 x1 = in0[SHIFT + lane], x2 = in0[SHIFT + 64 + lane], xs = in0[SHIFT + 144 + lane];
@@ -412,6 +450,7 @@ __global__ __launch_bounds__(64) void k_preamble(const c32 *__restrict__ iq0, co
         __syncthreads();
         if (s_ctl[0] != GR80211_ST_OK) goto finish;
     }
+    if (chanl_out) chanl_out[(size_t)f * 64 + bin] = hl;  // the "chan" tag of `signal` (lib/signal_impl.cc:143)
     nvalid = s_ctl[3];
     if (nvalid > navail - 224) nvalid = navail - 224;
 
@@ -683,7 +722,8 @@ finish:
         fi.nSym = m.nSym; fi.nSS = m.nSS; fi.nLTF = m.nLTF; fi.nCBPS = m.nCBPS; fi.nDBPS = m.nDBPS;
         fi.nBPSCS = m.nBPSCS; fi.mod = m.mod;
         fi.sssnr0 = s_snr[0]; fi.sssnr1 = s_snr[1];
-        fi.cfo_hz = rad * 3183098.8618379068f;  // rad * 20e6 / 2pi (lib/signal_impl.cc:136)
+        // rad * 20e6 / 2pi (lib/signal_impl.cc:136); `demod` hands the tag on as it came (lib/demod_impl.cc:82,225)
+        fi.cfo_hz = after_signal && sig ? sig[f].cfo : rad * 3183098.8618379068f;
         fi.snr = d.snr; fi.rssi = d.rssi;
         fi.slot = -1;
         fi.llr_off = 0;
@@ -1087,14 +1127,13 @@ __global__ __launch_bounds__(64 * DEMOD_WAVES) void k_demod(const c32 *__restric
     float *stage = s_stage[wave];
     const gr80211_frame_info fi = info[f];
     const gr80211_frame_desc d = descs[f];
-    uint64_t so;
-    const int navail = frame_window(d, arena_len, &so);
+    const c32 *b0, *b1;
+    const int navail = frame_origin(d, arena_len, iq0, iq1, &b0, &b1);
     const float rad = d.rad;
     int nvalid = fi.nsamp;
     if (nvalid > navail - 224) nvalid = navail - 224;
-    // a frame that got this far has its 224 preamble samples; one without data samples still needs an address
-    const uint64_t s0 = nvalid > 0 ? so + 224 : so;
-    const c32 *in0 = iq0 + s0;
+    // a frame without data samples still needs an address that can be read: the arena's first sample
+    const c32 *in0 = nvalid > 0 ? b0 + 224 : iq0;
 
     const int fmt = fi.format, nb = fi.nBPSCS, ncbps = fi.nCBPS, mod = fi.mod;
     const bool legacy = fmt == GR80211_F_L;
@@ -1156,7 +1195,7 @@ __global__ __launch_bounds__(64 * DEMOD_WAVES) void k_demod(const c32 *__restric
         }
     } else {
         // two spatial streams on two antennas (lib/demod2_impl.cc:504-550, 586-628)
-        const c32 *in1 = iq1 + s0;
+        const c32 *in1 = nvalid > 0 ? b1 + 224 : iq1;
         const bool pil = is_pilot_bin(bin);
         const c32 *c2 = chan2 + (size_t)f * CH2;
         c32 h[4], hi[4];
@@ -1747,9 +1786,8 @@ __global__ __launch_bounds__(256) void k_ndp_emit(const c32 *__restrict__ iq0, u
     if (out_stride < NBYTES + 3) return;  // no room: nothing is published, as for any PDU that does not fit
     const int lane = threadIdx.x & 63;
     const gr80211_frame_desc d = descs[f];
-    uint64_t so;
-    const int navail = frame_window(d, arena_len, &so);
-    const c32 *in0 = iq0 + so;
+    const c32 *in0, *unused;
+    const int navail = frame_origin(d, arena_len, iq0, nullptr, &in0, &unused);
     int nvalid = fi.nsamp;
     if (nvalid > navail - 224) nvalid = navail - 224;
     uint8_t *o = out + (size_t)f * out_stride;
@@ -1773,6 +1811,50 @@ __global__ __launch_bounds__(256) void k_ndp_emit(const c32 *__restrict__ iq0, u
     }
 }
 
+// Tags of `signal` -> descriptors of the kind the kernels above read.
+__global__ void k_sig_to_desc(const gr80211_sig_desc *__restrict__ sig, int n, gr80211_frame_desc *__restrict__ desc)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const gr80211_sig_desc sd = sig[i];
+    gr80211_frame_desc d;
+    d.sync_off = sd.off;
+    d.n_avail = sd.n_avail;
+    d.rad = 0.0f;  // `signal` has taken the CFO out
+    d.snr = sd.snr;
+    d.rssi = sd.rssi;
+    d.mu_pos = sd.mu_pos;
+    d.reserved = DESC_AFTER_SIGNAL;
+    desc[i] = d;
+}
+
+// The items `signal` writes for one frame (lib/signal_impl.cc:164-202): nsamp samples after L-SIG, CFO taken out,
+// then the 320 items of padding (zeros here, left unwritten by the reference).  One workgroup per frame.
+__global__ __launch_bounds__(256) void k_signal_copy(const c32 *__restrict__ iq0, const c32 *__restrict__ iq1,
+                                                     uint64_t arena_len, const gr80211_frame_desc *__restrict__ descs,
+                                                     int n, const gr80211_frame_info *__restrict__ info,
+                                                     const unsigned long long *__restrict__ out_off,
+                                                     c32 *__restrict__ out0, c32 *__restrict__ out1,
+                                                     unsigned long long out_len)
+{
+    const int f = blockIdx.x;
+    if (f >= n) return;
+    const gr80211_frame_info fi = info[f];
+    if (fi.status == GR80211_ST_DROP_LSIG) return;
+    const gr80211_frame_desc d = descs[f];
+    const c32 *in0, *in1;
+    const int navail = frame_origin(d, arena_len, iq0, iq1, &in0, &in1);
+    int nvalid = fi.nsamp;
+    if (nvalid > navail - 224) nvalid = navail - 224;
+    const unsigned long long o = out_off[f];
+    const int total = fi.nsamp + 320;
+    if (o > out_len || (unsigned long long)total > out_len - o) return;  // no room: the caller sized the arena wrongly
+    for (int k = threadIdx.x; k < total; k += blockDim.x) {
+        out0[o + k] = k < fi.nsamp ? load_samp(in0, k, nvalid, d.rad) : mk(0.0f, 0.0f);
+        if (out1) out1[o + k] = k < fi.nsamp && in1 ? load_samp(in1, k, nvalid, d.rad) : mk(0.0f, 0.0f);
+    }
+}
+
 __global__ void k_clear_outputs(int32_t *a, int32_t *b, int n)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1783,10 +1865,22 @@ __global__ void k_clear_outputs(int32_t *a, int32_t *b, int n)
 // launchers
 // =========================================================================================
 void launch_preamble(const void *iq0, const void *iq1, uint64_t arena_len, const gr80211_frame_desc *desc, int n,
-                     gr80211_frame_info *info, void *chan1, void *chan2, hipStream_t s)
+                     gr80211_frame_info *info, void *chan1, void *chan2, const gr80211_sig_desc *sig, const void *chan_in,
+                     void *chanl_out, hipStream_t s)
 {
     hipLaunchKernelGGL(k_preamble, dim3(n), dim3(64), 0, s, (const c32 *)iq0, (const c32 *)iq1, arena_len, desc, n,
-                       info, (c32 *)chan1, (c32 *)chan2);
+                       info, (c32 *)chan1, (c32 *)chan2, sig, (const c32 *)chan_in, (c32 *)chanl_out);
+}
+void launch_sig_to_desc(const gr80211_sig_desc *sig, int n, gr80211_frame_desc *desc, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_sig_to_desc, dim3((n + 255) / 256), dim3(256), 0, s, sig, n, desc);
+}
+void launch_signal_copy(const void *iq0, const void *iq1, uint64_t arena_len, const gr80211_frame_desc *desc, int n,
+                        const gr80211_frame_info *info, const uint64_t *out_off, void *out0, void *out1, uint64_t out_len,
+                        hipStream_t s)
+{
+    hipLaunchKernelGGL(k_signal_copy, dim3(n), dim3(256), 0, s, (const c32 *)iq0, (const c32 *)iq1, arena_len, desc, n,
+                       info, (const unsigned long long *)out_off, (c32 *)out0, (c32 *)out1, (unsigned long long)out_len);
 }
 void launch_desc_to_info(const gr80211_dec_desc *desc, int n, uint64_t llr_floats, gr80211_frame_info *info, hipStream_t s)
 {

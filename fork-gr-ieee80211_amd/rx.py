@@ -46,6 +46,10 @@ FRAME_INFO_DTYPE = np.dtype(
                           "trellis", "total", "nSym", "nSS", "nLTF", "nCBPS", "nDBPS", "nBPSCS", "mod")] +
     [("sssnr0", "<f4"), ("sssnr1", "<f4"), ("cfo_hz", "<f4"), ("snr", "<f4"), ("rssi", "<f4"),
      ("slot", "<i4"), ("llr_off", "<i8"), ("data_off", "<i4"), ("nSymSamp", "<i4")])
+SIG_DESC_DTYPE = np.dtype([("off", "<u8"), ("n_avail", "<u4"), ("mcs", "<i4"), ("len", "<i4"), ("nsamp", "<i4"),
+                           ("cfo", "<f4"), ("snr", "<f4"), ("rssi", "<f4"), ("mu_pos", "<u4"), ("reserved", "<u4"),
+                           ("pad", "<u4")])
+assert SIG_DESC_DTYPE.itemsize == 48
 DEC_DESC_DTYPE = np.dtype([("llr_off", "<i8"), ("n_llr", "<i4"), ("format", "<i4"), ("len", "<i4"),
                            ("cr", "<i4"), ("mcs", "<i4"), ("ampdu", "<i4"), ("trellis", "<i4"),
                            ("reserved", "<i4")])
@@ -66,7 +70,7 @@ EXPORTS = [
     "gr80211_demod_batch", "gr80211_decode_batch", "gr80211_dev_alloc", "gr80211_dev_free",
     "gr80211_copy_h2d", "gr80211_copy_d2h", "gr80211_set_profiling", "gr80211_last_timing",
     "gr80211_version", "gr80211_table_checksum", "gr80211_tx_samples", "gr80211_tx_batch", "gr80211_set_mu_pos", "gr80211_set_ampdu_strict", "gr80211_tx_mu_batch",
-    "gr80211_host_alloc", "gr80211_host_free", "gr80211_copy_d2d",
+    "gr80211_host_alloc", "gr80211_host_free", "gr80211_copy_d2d", "gr80211_signal_emit_batch", "gr80211_demod_tagged_batch",
 ]
 
 _lib = None
@@ -103,6 +107,9 @@ def load_library():
     L.gr80211_host_alloc.argtypes = [vp, C.c_size_t]
     L.gr80211_host_alloc.restype = vp
     L.gr80211_copy_d2d.argtypes = [vp, vp, vp, C.c_size_t, vp]
+    L.gr80211_signal_emit_batch.argtypes = [vp, vp, vp, C.c_uint64, vp, C.c_int, C.c_uint, vp, vp, vp, C.c_uint64, vp, vp, vp]
+    L.gr80211_demod_tagged_batch.argtypes = [vp, vp, vp, C.c_uint64, vp, C.c_int, C.c_uint, vp, vp, C.POINTER(vp),
+                                             C.POINTER(C.c_uint64), vp]
     L.gr80211_host_free.argtypes = [vp, vp]
     L.gr80211_host_free.restype = None
     L.gr80211_dev_free.argtypes = [vp, vp]
@@ -319,6 +326,47 @@ class RxContext:
                                                   int(nfl.value) * 4, self._stream()), "copy_d2h")
         info_h = info.cpu().numpy().view(FRAME_INFO_DTYPE)
         return info_h, llr[: int(nfl.value)]
+
+    def signal_emit(self, iq0, iq1, desc, n_frames, out_off, out_items):
+        """`signal` alone: (info ndarray, chan [n, 64] complex64 ndarray, out0, out1 CUDA tensors).  out_off: item
+        offset of every frame in the output (host array of uint64)."""
+        t = self.torch
+        info = t.empty(max(n_frames, 1) * FRAME_INFO_DTYPE.itemsize, dtype=t.uint8, device=self.dev)
+        chan = t.zeros((max(n_frames, 1), 64), dtype=t.complex64, device=self.dev)
+        out0 = t.zeros(max(out_items, 1), dtype=t.complex64, device=self.dev)
+        out1 = t.zeros(max(out_items, 1), dtype=t.complex64, device=self.dev) if iq1 is not None else None
+        dp, flags, keep = self._desc_arg(desc)
+        assert flags == 0, "host descriptors"
+        off = np.ascontiguousarray(out_off, dtype=np.uint64)
+        rc = self.lib.gr80211_signal_emit_batch(
+            self.h, C.c_void_p(iq0.data_ptr()), C.c_void_p(iq1.data_ptr()) if iq1 is not None else None, iq0.numel(), dp,
+            n_frames, 0, C.c_void_p(off.ctypes.data), C.c_void_p(out0.data_ptr()),
+            C.c_void_p(out1.data_ptr()) if out1 is not None else None, out_items, C.c_void_p(info.data_ptr()),
+            C.c_void_p(chan.data_ptr()), self._stream())
+        self._check(rc, "gr80211_signal_emit_batch")
+        self.sync()
+        return info.cpu().numpy().view(FRAME_INFO_DTYPE)[:n_frames], chan.cpu().numpy()[:n_frames], out0, out1
+
+    def demod_tagged(self, iq0, iq1, sig_desc, n_frames, chan):
+        """`demod` alone, from `signal`'s items and tags: (info ndarray, llr ndarray on host).  sig_desc: SIG_DESC_DTYPE
+        ndarray; chan: [n, 64] complex64 (ndarray or CUDA tensor)."""
+        t = self.torch
+        info = t.empty(max(n_frames, 1) * FRAME_INFO_DTYPE.itemsize, dtype=t.uint8, device=self.dev)
+        d_chan = chan if isinstance(chan, t.Tensor) else t.from_numpy(np.ascontiguousarray(chan, np.complex64)).to(self.dev)
+        sd = np.ascontiguousarray(sig_desc)
+        llr_ptr = C.c_void_p()
+        nfl = C.c_uint64(0)
+        rc = self.lib.gr80211_demod_tagged_batch(
+            self.h, C.c_void_p(iq0.data_ptr()), C.c_void_p(iq1.data_ptr()) if iq1 is not None else None, iq0.numel(),
+            C.c_void_p(sd.ctypes.data), n_frames, 0, C.c_void_p(d_chan.data_ptr()), C.c_void_p(info.data_ptr()),
+            C.byref(llr_ptr), C.byref(nfl), self._stream())
+        self._check(rc, "gr80211_demod_tagged_batch")
+        self.sync()
+        llr = np.zeros(max(int(nfl.value), 1), dtype=np.float32)
+        if nfl.value:
+            self._check(self.lib.gr80211_copy_d2h(self.h, C.c_void_p(llr.ctypes.data), llr_ptr,
+                                                  int(nfl.value) * 4, self._stream()), "copy_d2h")
+        return info.cpu().numpy().view(FRAME_INFO_DTYPE)[:n_frames], llr[: int(nfl.value)]
 
     def decode_batch(self, llr, desc, n_frames, out_stride=4104, want_bits=False, bits_stride=4104):
         """LLRs -> PDUs.  llr: float32 CUDA tensor; desc: DEC_DESC_DTYPE ndarray or device bytes."""

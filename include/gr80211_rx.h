@@ -65,7 +65,7 @@ typedef struct {
     float rssi;
     uint32_t mu_pos;   /* this station's position (0 or 1) in a VHT MU group: the mupos argument of
                           ieee80211::demod::make(mupos, mugid) (lib/demod_impl.cc:28-39); only read for MU frames */
-    uint32_t reserved;
+    uint32_t reserved; /* 0 */
 } gr80211_frame_desc; /* 32 bytes */
 
 /*
@@ -96,6 +96,23 @@ typedef struct {
     int32_t format, len, cr, mcs, ampdu, trellis;
     int32_t reserved;
 } gr80211_dec_desc; /* 40 bytes */
+
+/*
+ * What `signal` tells `demod` with the tags on the first item of a frame (lib/signal_impl.cc:135-152, read at
+ * lib/demod_impl.cc:75-100): the frame's items start right after L-SIG and have the CFO taken out.
+ */
+typedef struct {
+    uint64_t off;     /* index of the frame's first item in the arena(s) */
+    uint32_t n_avail; /* items of the frame the arena holds from there (nsamp, or fewer at the end of a stream) */
+    int32_t mcs;      /* tag "mcs": L-SIG rate 0..7 */
+    int32_t len;      /* tag "len": L-SIG length */
+    int32_t nsamp;    /* tag "nsamp": 80 * symbols the L-SIG announces */
+    float cfo;        /* tags "cfo", "snr", "rssi": handed on unchanged */
+    float snr;
+    float rssi;
+    uint32_t mu_pos;  /* as in gr80211_frame_desc */
+    uint32_t reserved;
+} gr80211_sig_desc; /* 48 bytes */
 
 #define GR80211_FLAG_DESC_ON_DEVICE 1u /* the descriptor array argument is a device pointer */
 
@@ -262,6 +279,31 @@ int gr80211_tx_batch(gr80211_ctx *ctx, const uint8_t *d_psdu, uint64_t psdu_byte
 int gr80211_tx_mu_batch(gr80211_ctx *ctx, const uint8_t *d_psdu, uint64_t psdu_bytes, const gr80211_tx_mu_desc *desc,
                         int n_frames, unsigned flags, const void *d_q, int n_q, void *d_iq0, void *d_iq1,
                         uint64_t arena_len, int32_t *d_n_samples, void *stream);
+
+/*
+ * `signal` / `signal2` alone (lib/signal_impl.cc:108-202, lib/signal2_impl.cc): for every descriptor the L-SIG
+ * decision and tags (d_info: status, lsig_mcs, lsig_len, nsamp, cfo_hz, snr, rssi), the L-LTF channel estimate of
+ * the first antenna that travels as tag "chan" (d_chan: 64 complex64 per frame, FFT bin order), and the items the
+ * block writes: nsamp samples after L-SIG with the CFO taken out, then 320 items of padding (zeros here; the
+ * reference leaves them unwritten), at item out_off[i] of d_out0 (and d_out1 for the second antenna).  out_off is
+ * a host array unless GR80211_FLAG_DESC_ON_DEVICE is set (then both arrays are device arrays); frames whose L-SIG
+ * check fails write nothing.  A caller learns nsamp with gr80211_signal_batch first and lays the output out.
+ */
+int gr80211_signal_emit_batch(gr80211_ctx *ctx, const void *d_iq0, const void *d_iq1, uint64_t arena_len,
+                              const gr80211_frame_desc *desc, int n_frames, unsigned flags, const uint64_t *out_off,
+                              void *d_out0, void *d_out1, uint64_t out_len, gr80211_frame_info *d_info, void *d_chan,
+                              void *stream);
+
+/*
+ * `demod` / `demod2` alone (lib/demod_impl.cc:59-342, lib/demod2_impl.cc:58-349): frames as `signal` hands them
+ * on -- items after L-SIG in d_iq0 (d_iq1), the tags in desc, the "chan" vectors in d_chan (64 complex64 per frame)
+ * -- to soft bits and the tags `demod` attaches to them, exactly as gr80211_demod_batch returns them.  Tags a
+ * correct `signal` cannot have produced (mcs outside 0..7, len outside 1..4095, nsamp not matching them) give
+ * status GR80211_ST_DROP_LSIG.
+ */
+int gr80211_demod_tagged_batch(gr80211_ctx *ctx, const void *d_iq0, const void *d_iq1, uint64_t arena_len,
+                               const gr80211_sig_desc *desc, int n_frames, unsigned flags, const void *d_chan,
+                               gr80211_frame_info *d_info, const float **d_llr, uint64_t *llr_floats, void *stream);
 
 /* Device memory helpers so that a C / FFI caller needs no HIP binding of its own. */
 void *gr80211_dev_alloc(gr80211_ctx *ctx, size_t bytes);

@@ -342,3 +342,63 @@ def test_ampdu_strict_deaggregation(pkg, rxctx, oracle):
         assert [p["mpdu"] for p in tight[2]["pdus"]] == hs
     finally:
         strict_ctx.close()
+
+
+def test_signal_and_demod_as_separate_stages(pkg, rxctx, oracle):
+    """`signal` alone writes the items and tags the reference block writes (lib/signal_impl.cc:135-202): nsamp
+    samples after L-SIG with the CFO taken out, 320 items of padding, L-SIG rate / length and the L-LTF channel;
+    `demod` alone, fed with exactly those, returns the soft bits and tags of the fused path bit for bit, and they
+    agree with the oracle's."""
+    import torch
+    from util import H22, build_arena, golden_frames
+    for two in (False, True):
+        frames = [f for f in golden_frames() if (f["nss"] == 2) == two]
+        if two:
+            srcs = [([r[0], r[1]], f["sync_idx"]) for f in frames for r in [(H22 @ f["iq"]).astype(np.complex64)]]
+        else:
+            srcs = [([f["iq"][0]], f["sync_idx"]) for f in frames]
+        iq0, iq1, sync, navail = build_arena(srcs)
+        rads = np.array([f["rad"] for f in frames], np.float32)
+        n = len(frames)
+        d0 = torch.from_numpy(iq0).cuda()
+        d1 = torch.from_numpy(iq1).cuda() if two else None
+        desc = rxctx.make_desc(sync, navail, rad=rads)
+        probe = rxctx.signal_batch(d0, d1, desc, n)
+        assert (probe["status"] != 1).all()
+        out_off = np.concatenate([[0], np.cumsum(probe["nsamp"].astype(np.int64) + 320)])
+        info, chan, o0, o1 = rxctx.signal_emit(d0, d1, desc, n, out_off[:-1], int(out_off[-1]))
+        h0 = o0.cpu().numpy()
+        for i, f in enumerate(frames):
+            ns = int(info["nsamp"][i])
+            assert ns == int(probe["nsamp"][i]) and int(info["lsig_len"][i]) == int(probe["lsig_len"][i])
+            k = np.arange(ns)
+            src = iq0[int(sync[i]) + 224:int(sync[i]) + 224 + ns]
+            want = src * np.exp(1j * (k + 224) * np.float64(rads[i]))
+            got = h0[out_off[i]:out_off[i] + ns]
+            assert np.abs(got - want).max() < 2e-5 * max(1.0, np.abs(src).max())
+            assert not h0[out_off[i] + ns:out_off[i] + ns + 320].any()
+            ref = oracle.rx_frame(iq0[: int(sync[i]) + int(navail[i])], iq1[: int(sync[i]) + int(navail[i])] if two else None,
+                                  int(sync[i]), float(rads[i]), want_llr=True)
+            assert int(info["lsig_mcs"][i]) == ref["frame"].lsig_mcs and int(info["lsig_len"][i]) == ref["frame"].lsig_len
+        # demod alone from those items and tags
+        sd = np.zeros(n, dtype=pkg.rx.SIG_DESC_DTYPE)
+        sd["off"], sd["n_avail"] = out_off[:-1], info["nsamp"]
+        sd["mcs"], sd["len"], sd["nsamp"] = info["lsig_mcs"], info["lsig_len"], info["nsamp"]
+        sd["cfo"], sd["snr"], sd["rssi"] = info["cfo_hz"], info["snr"], info["rssi"]
+        info2, llr2 = rxctx.demod_tagged(o0, o1, sd, n, chan)
+        info1, llr1 = rxctx.demod_batch(d0, d1, desc, n)
+        for key in ("status", "format", "mcs", "len", "cr", "ampdu", "trellis", "total", "nSym", "nSS", "cfo_hz"):
+            assert np.array_equal(info1[key], info2[key]), key
+        for i in range(n):
+            a = llr1[int(info1["llr_off"][i]):int(info1["llr_off"][i]) + int(info1["total"][i])]
+            b = llr2[int(info2["llr_off"][i]):int(info2["llr_off"][i]) + int(info2["total"][i])]
+            if rads[i] == 0.0:
+                assert np.array_equal(a, b), i          # same samples, same arithmetic
+            else:
+                assert np.allclose(a, b, rtol=1e-3, atol=2e-3), i   # derotated once more: rounded differently
+    # tags a correct `signal` cannot have sent are refused
+    bad = sd.copy()
+    bad["nsamp"][0] += 80
+    bad["mcs"][1] = 9
+    info3, _ = rxctx.demod_tagged(o0, o1, bad, n, chan)
+    assert int(info3["status"][0]) == 1 and int(info3["status"][1]) == 1 and int(info3["status"][2]) == int(info2["status"][2])
