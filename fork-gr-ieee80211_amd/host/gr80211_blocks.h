@@ -7,6 +7,11 @@
 //                             ieee80211::signal/signal2 (lib/signal_impl.cc:34-106, lib/signal2_impl.cc:34-110:
 //                             sync byte stream with tags rad/snr/rssi + one or two complex sample streams) and
 //                             the output contract of ieee80211::decode (message port "out").
+//   gr80211::host::signal  -- drop-in for ieee80211::signal / signal2 (lib/signal_impl.cc, lib/signal2_impl.cc):
+//                             the same inputs, the frames' items after L-SIG with the tags cfo, snr, rssi, seq, mcs,
+//                             len, nsamp, chan out.
+//   gr80211::host::demod   -- drop-in for ieee80211::demod / demod2 (lib/demod_impl.cc, lib/demod2_impl.cc): those
+//                             items and tags in, soft bits with the tags decode reads out.
 //
 // GNU Radio itself is not a dependency: `block` below carries the few scheduler services those blocks use
 // (nitems_read, get_tags_in_range, consume_each, message_port_pub), so a gr::block wrapper only forwards.
@@ -20,6 +25,7 @@
 #include <functional>
 #include <memory>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/gr80211_rx.h"
@@ -61,13 +67,21 @@ public:
     void clear_item_tags_in() { for (auto &tv : d_tags) tv.clear(); }
     void set_msg_handler(std::function<void(const std::string &port, const pdu_t &msg)> f) { d_handler = std::move(f); }
     uint64_t nitems_read(int port) const { return d_read[port]; }
+    uint64_t nitems_written(int port) const { return d_written[port]; }
+    int n_outputs() const { return (int)d_written.size(); }
     int consumed() const { return d_consumed; }  // items consumed by the last general_work call (every port)
-    void commit();                               // advance nitems_read by consumed(), forget passed tags
+    // advance nitems_read by consumed() and nitems_written by `produced` (what general_work returned), forget
+    // passed tags
+    void commit(int produced = 0);
+    // tags general_work attached to the items it has just produced on `port` (absolute offsets); the scheduler
+    // takes them with every call
+    std::vector<tag_t> take_output_tags(int port);
     const std::string &last_error() const { return d_err; }
 
 protected:
-    explicit block(int n_in);
+    explicit block(int n_in, int n_out = 0);
     void consume_each(int n) { d_consumed = n; }
+    void add_item_tag(int port, const tag_t &t) { d_out_tags[port].push_back(t); }
     void get_tags_in_range(std::vector<tag_t> &v, int port, uint64_t start, uint64_t end) const;
     void message_port_pub(const std::string &port, const pdu_t &m);
     // Publishes the messages n frame slots hold (stride bytes apart, len[i] bytes used); returns how many.
@@ -75,7 +89,8 @@ protected:
     std::string d_err;
 
 private:
-    std::vector<uint64_t> d_read;
+    std::vector<uint64_t> d_read, d_written;
+    std::vector<std::vector<tag_t>> d_out_tags;
     std::vector<std::deque<tag_t>> d_tags;  // per port, sorted by offset; passed tags leave at the front
     int d_consumed = 0;
     std::function<void(const std::string &, const pdu_t &)> d_handler;
@@ -133,6 +148,28 @@ private:
     size_t d_n = 0, d_cap = 0;              // in items
 };
 
+// Items a block has produced and the scheduler has not yet made room for, with their tags (offsets count the
+// items ever pushed).
+class out_stream
+{
+public:
+    explicit out_stream(size_t item_bytes) : d_item(item_bytes) {}
+    uint64_t pushed() const { return d_pushed; }
+    size_t pending() const { return (d_buf.size() - d_head) / d_item; }
+    void push(const void *src, size_t items);
+    void push_zeros(size_t items);
+    void tag(const tag_t &t) { d_tags.push_back(t); }  // t.offset = index among the pushed items
+    // up to max_items into dst; their tags into `out`, re-based to the port's absolute offset `written`
+    int pop(void *dst, int max_items, uint64_t written, std::vector<tag_t> &out);
+
+private:
+    size_t d_item;
+    std::vector<uint8_t> d_buf;
+    size_t d_head = 0;         // bytes of d_buf already popped
+    uint64_t d_pushed = 0, d_popped = 0;
+    std::deque<tag_t> d_tags;
+};
+
 class decode : public block
 {
 public:
@@ -164,6 +201,8 @@ private:
     long t_nProcd = 0;
     device_fifo d_llr;                        // soft bits of the pending packets, back to back
     std::vector<gr80211_dec_desc> d_desc;     // one per pending packet
+    std::vector<std::pair<size_t, pdu_t>> d_ready;  // channel messages of sounding packets and how many pending
+                                                    // packets precede each
     uint64_t d_nSeen = 0, d_nPdu = 0;
 };
 
@@ -187,15 +226,25 @@ public:
     uint64_t frames_decoded() const { return d_nFrames; }
     uint64_t pdus_published() const { return d_nPdu; }
 
-private:
-    rx(int n_rx, int batch_frames, int device);
+protected:
+    rx(int n_rx, int batch_frames, int device, int n_out = 0);
+    struct frame_ref {
+        uint64_t pos;  // absolute item index of the trigger byte
+        int mcs, len, nsamp;
+        float rad, snr, rssi;
+    };
+    // What becomes of the frames of one round: fd[i] describes frame i in the device arenas diq0 / diq1 (nheld items
+    // each).  rx decodes them and publishes their PDUs.
+    virtual bool handle_frames(const void *diq0, const void *diq1, size_t nheld, std::vector<gr80211_frame_desc> &fd,
+                               const std::vector<frame_ref> &fr);
+    int take_input(gr_vector_int &ninput_items, gr_vector_const_void_star &input_items);  // items consumed, -1 on error
     bool process(bool final);
 
     struct trigger {
         uint64_t pos;  // absolute item index of the sync byte
         float rad, snr, rssi;
         bool probed;
-        int status, nsamp;
+        int status, nsamp, mcs, len;
     };
     int d_nrx, d_batch;
     int d_muPos = 0;
@@ -207,6 +256,62 @@ private:
     std::vector<trigger> d_trig;
     size_t d_maxHold;
     uint64_t d_nTrig = 0, d_nFrames = 0, d_nPdu = 0;
+};
+
+// ieee80211::signal (n_rx = 1: in {u8 sync, c64}, out {c64}) and signal2 (n_rx = 2: in {u8, c64, c64}, out {c64, c64}),
+// include/gnuradio/ieee80211/signal.h:22-36, lib/signal_impl.cc:34-206: per frame nsamp items after L-SIG with the
+// CFO taken out, then 320 items of padding, with the tags cfo, snr, rssi, seq, mcs, len, nsamp and chan on the first
+// one.  The trigger search is the fused block's; the items leave as the scheduler makes room for them.
+class signal : public rx
+{
+public:
+    typedef std::shared_ptr<signal> sptr;
+    static sptr make(int n_rx = 1, int batch_frames = 4096, int device = 0);
+    int general_work(int noutput_items, gr_vector_int &ninput_items, gr_vector_const_void_star &input_items,
+                     gr_vector_void_star &output_items) override;
+    size_t pending_output() const { return d_out0.pending(); }
+
+protected:
+    signal(int n_rx, int batch_frames, int device);
+    bool handle_frames(const void *diq0, const void *diq1, size_t nheld, std::vector<gr80211_frame_desc> &fd,
+                       const std::vector<frame_ref> &fr) override;
+
+private:
+    out_stream d_out0, d_out1;
+    long d_seq = 0;
+};
+
+// ieee80211::demod(mupos, mugid) (n_rx = 1: in {c64}) and demod2 (n_rx = 2: in {c64, c64}), out {f32},
+// include/gnuradio/ieee80211/demod.h:22-36, lib/demod_impl.cc:59-342, lib/demod2_impl.cc:58-349: reads signal's tags
+// on the first item of a frame, takes nsamp + 320 items, writes the frame's soft bits with the tags cfo, snr, rssi,
+// format, mcs, len, cr, ampdu, trellis, total (and sssnr0 / sssnr1 for VHT) on the first one.  Frames it cannot
+// demodulate leave nothing, as in the reference.
+class demod : public block
+{
+public:
+    typedef std::shared_ptr<demod> sptr;
+    static sptr make(int n_rx = 1, int mupos = 0, int mugid = 2, int batch_frames = 4096, int device = 0);
+    void forecast(int noutput_items, gr_vector_int &ninput_items_required) override;
+    int general_work(int noutput_items, gr_vector_int &ninput_items, gr_vector_const_void_star &input_items,
+                     gr_vector_void_star &output_items) override;
+    bool flush() override;
+    size_t pending_output() const { return d_out.pending(); }
+    uint64_t frames_seen() const { return d_nSeen; }
+    void set_mu_pos(int pos) { d_muPos = pos ? 1 : 0; }
+
+private:
+    demod(int n_rx, int mupos, int batch_frames, int device);
+    bool run_batch();
+    int d_nrx, d_muPos, d_batch;
+    gpu_session d_gpu;
+    device_fifo d_iq0, d_iq1;
+    device_fifo &iq(int a) { return a ? d_iq1 : d_iq0; }
+    enum { S_IDLE, S_COLLECT, S_CLEAN } d_state = S_IDLE;
+    long d_need = 0, d_skip = 0;            // items of the current frame still to collect / to pass over
+    std::vector<gr80211_sig_desc> d_desc;   // one per pending frame
+    std::vector<gr_complex> d_chan;         // 64 per pending frame
+    out_stream d_out;
+    uint64_t d_nSeen = 0;
 };
 
 // Whole receive flowgraph of examples/rx.grc / rx2.grc for a recorded capture: inputs are the antenna streams only

@@ -11,16 +11,20 @@ struct gr80211_block {
     std::shared_ptr<block> b;
     int kind = 0;
     int n_in = 1;
+    int n_out = 0;
     gr80211_msg_fn fn = nullptr;
     void *user = nullptr;
     std::string err;
+    std::vector<tag_t> out_tags;  // of the last call: the records handed out point into them
 };
 
 namespace {
 
 thread_local std::string g_create_err = "null block";
 
-const char *const kTagNames[] = {"rad", "snr", "rssi", "format", "len", "total", "cr", "mcs", "ampdu", "trellis", "mu2x1chan"};
+const char *const kTagNames[] = {"rad", "snr", "rssi", "format", "len", "total", "cr", "mcs", "ampdu", "trellis", "mu2x1chan",
+                                 "cfo", "seq", "nsamp", "chan", "sssnr0", "sssnr1"};
+const int kNumTags = (int)(sizeof(kTagNames) / sizeof(kTagNames[0]));
 
 }  // namespace
 
@@ -37,6 +41,10 @@ gr80211_block *gr80211_block_create(int kind, int batch_frames, int device)
     case GR80211_BLOCK_RX2: h->b = rx::make(2, batch, device); h->n_in = 3; break;
     case GR80211_BLOCK_CAPTURE: h->b = capture_rx::make(1, device); h->n_in = 1; break;
     case GR80211_BLOCK_CAPTURE2: h->b = capture_rx::make(2, device); h->n_in = 2; break;
+    case GR80211_BLOCK_SIGNAL: h->b = signal::make(1, batch, device); h->n_in = 2; h->n_out = 1; break;
+    case GR80211_BLOCK_SIGNAL2: h->b = signal::make(2, batch, device); h->n_in = 3; h->n_out = 2; break;
+    case GR80211_BLOCK_DEMOD: h->b = demod::make(1, 0, 2, batch, device); h->n_in = 1; h->n_out = 1; break;
+    case GR80211_BLOCK_DEMOD2: h->b = demod::make(2, 0, 2, batch, device); h->n_in = 2; h->n_out = 1; break;
     default: g_create_err = "gr80211_block_create: unknown block kind"; return nullptr;
     }
     if (!h->b || !h->b->last_error().empty()) {
@@ -65,10 +73,12 @@ int gr80211_block_set_option(gr80211_block *b, int option, int value)
     decode *d = dynamic_cast<decode *>(b->b.get());
     rx *r = dynamic_cast<rx *>(b->b.get());
     capture_rx *c = dynamic_cast<capture_rx *>(b->b.get());
+    demod *dm = dynamic_cast<demod *>(b->b.get());
     if (option == GR80211_OPT_MU_POS) {
         if (value < 0 || value > 1 || d) return -1;
         if (r) r->set_mu_pos(value);
         if (c) c->set_mu_pos(value);
+        if (dm) dm->set_mu_pos(value);
         return 0;
     }
     if (option == GR80211_OPT_AMPDU_STRICT) {
@@ -91,15 +101,35 @@ int gr80211_block_forecast(gr80211_block *b, int noutput_items, int *ninput_item
     return 0;
 }
 
+int gr80211_block_n_outputs(const gr80211_block *b) { return b ? b->n_out : -1; }
+
+long long gr80211_block_pending_output(const gr80211_block *b)
+{
+    if (!b) return -1;
+    if (const signal *sg = dynamic_cast<const signal *>(b->b.get())) return (long long)sg->pending_output();
+    if (const demod *dm = dynamic_cast<const demod *>(b->b.get())) return (long long)dm->pending_output();
+    return 0;
+}
+
 int gr80211_block_work(gr80211_block *b, int noutput_items, const int *ninput_items, const void *const *input_items,
                        int n_inputs, const gr80211_tag *tags, int n_tags, int *consumed)
 {
+    return gr80211_block_work_out(b, noutput_items, ninput_items, input_items, n_inputs, tags, n_tags, nullptr, 0, nullptr, 0,
+                                  nullptr, consumed);
+}
+
+int gr80211_block_work_out(gr80211_block *b, int noutput_items, const int *ninput_items, const void *const *input_items,
+                           int n_inputs, const gr80211_tag *tags, int n_tags, void *const *output_items, int n_outputs,
+                           gr80211_tag *tags_out, int cap_tags_out, int *n_tags_out, int *consumed)
+{
     if (!b || !ninput_items || !input_items || n_inputs != b->n_in || n_tags < 0 || (n_tags > 0 && !tags)) return -1;
+    if (n_outputs != 0 && (n_outputs != b->n_out || !output_items)) return -1;
+    if (n_tags_out) *n_tags_out = 0;
     // the caller hands over every tag of the offered windows with each call, so nothing is kept between calls
     b->b->clear_item_tags_in();
     for (int i = 0; i < n_tags; i++) {
         const gr80211_tag &t = tags[i];
-        if (t.port >= (uint32_t)n_inputs || t.key > GR80211_TAG_MU2X1CHAN) {
+        if (t.port >= (uint32_t)n_inputs || t.key >= (uint32_t)kNumTags) {
             b->err = "gr80211_block_work: bad tag";
             return -1;
         }
@@ -114,9 +144,32 @@ int gr80211_block_work(gr80211_block *b, int noutput_items, const int *ninput_it
     gr_vector_int nin(ninput_items, ninput_items + n_inputs);
     gr_vector_const_void_star in(input_items, input_items + n_inputs);
     gr_vector_void_star out;
+    for (int i = 0; i < n_outputs; i++) out.push_back(output_items[i]);
     const int produced = b->b->general_work(noutput_items, nin, in, out);
     if (consumed) *consumed = b->b->consumed();
-    b->b->commit();
+    b->out_tags.clear();
+    for (int p = 0; p < b->b->n_outputs(); p++) {
+        std::vector<tag_t> t = b->b->take_output_tags(p);
+        for (tag_t &x : t) b->out_tags.push_back(std::move(x));  // only port 0 carries tags in these blocks
+    }
+    int nt = 0;
+    for (const tag_t &x : b->out_tags) {
+        if (!tags_out || nt >= cap_tags_out) break;
+        int key = -1;
+        for (int k = 0; k < kNumTags; k++)
+            if (x.key == kTagNames[k]) key = k;
+        if (key < 0) continue;
+        gr80211_tag &o = tags_out[nt++];
+        o.offset = x.offset;
+        o.port = 0;
+        o.key = (uint32_t)key;
+        o.value = x.value;
+        o.cvec = x.cvec.empty() ? nullptr : reinterpret_cast<const float *>(x.cvec.data());
+        o.cvec_len = (uint32_t)x.cvec.size();
+        o.reserved = 0;
+    }
+    if (n_tags_out) *n_tags_out = nt;
+    b->b->commit(produced);
     if (!b->b->last_error().empty()) {
         b->err = b->b->last_error();
         return -2;

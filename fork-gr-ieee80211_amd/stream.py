@@ -8,12 +8,15 @@ import numpy as np
 
 from . import rx as _rx
 
-DECODE, RX, RX2, CAPTURE, CAPTURE2 = range(5)
-TAG_KEYS = ("rad", "snr", "rssi", "format", "len", "total", "cr", "mcs", "ampdu", "trellis", "mu2x1chan")
+DECODE, RX, RX2, CAPTURE, CAPTURE2, SIGNAL, SIGNAL2, DEMOD, DEMOD2 = range(9)
+TAG_KEYS = ("rad", "snr", "rssi", "format", "len", "total", "cr", "mcs", "ampdu", "trellis", "mu2x1chan",
+            "cfo", "seq", "nsamp", "chan", "sssnr0", "sssnr1")
+OUT_DTYPES = {SIGNAL: np.complex64, SIGNAL2: np.complex64, DEMOD: np.float32, DEMOD2: np.float32}
 OPT_MU_POS, OPT_AMPDU_STRICT = 0, 1
 EXPORTS = ("gr80211_block_create", "gr80211_block_destroy", "gr80211_block_set_msg_handler",
            "gr80211_block_set_option", "gr80211_block_n_inputs", "gr80211_block_forecast", "gr80211_block_work",
-           "gr80211_block_flush", "gr80211_block_last_error")
+           "gr80211_block_flush", "gr80211_block_last_error", "gr80211_block_n_outputs", "gr80211_block_work_out",
+           "gr80211_block_pending_output")
 
 
 class Tag(ctypes.Structure):
@@ -48,6 +51,12 @@ def load_host_library():
     L.gr80211_block_forecast.argtypes = [vp, ci, ctypes.POINTER(ci), ci]
     L.gr80211_block_work.argtypes = [vp, ci, ctypes.POINTER(ci), ctypes.POINTER(vp), ci, ctypes.POINTER(Tag), ci,
                                      ctypes.POINTER(ci)]
+    L.gr80211_block_n_outputs.argtypes = [vp]
+    L.gr80211_block_work_out.argtypes = [vp, ci, ctypes.POINTER(ci), ctypes.POINTER(vp), ci, ctypes.POINTER(Tag), ci,
+                                         ctypes.POINTER(vp), ci, ctypes.POINTER(Tag), ci, ctypes.POINTER(ci),
+                                         ctypes.POINTER(ci)]
+    L.gr80211_block_pending_output.restype = ctypes.c_longlong
+    L.gr80211_block_pending_output.argtypes = [vp]
     L.gr80211_block_flush.argtypes = [vp]
     L.gr80211_block_last_error.restype = ctypes.c_char_p
     L.gr80211_block_last_error.argtypes = [vp]
@@ -66,6 +75,9 @@ class StreamBlock:
             raise RuntimeError(self.lib.gr80211_block_last_error(None).decode())
         self.kind = kind
         self.n_in = self.lib.gr80211_block_n_inputs(self.h)
+        self.n_out = self.lib.gr80211_block_n_outputs(self.h)
+        self.out = [[] for _ in range(self.n_out)]  # arrays produced on every output port
+        self.out_tags = []                          # (offset, key name, value, complex vector or None)
         self.msgs = []
         self._cb = MSG_FN(lambda user, p, n: self.msgs.append(ctypes.string_at(p, n)))
         self.lib.gr80211_block_set_msg_handler(self.h, self._cb, None)
@@ -94,9 +106,10 @@ class StreamBlock:
         self._check(self.lib.gr80211_block_forecast(self.h, noutput_items, req, self.n_in), "forecast")
         return list(req)
 
-    def work(self, windows, tags=()):
+    def work(self, windows, tags=(), noutput_items=8192):
         """One general_work call.  windows: one contiguous numpy array per input port; tags: (offset, port, key
-        name, value[, complex vector]) inside the windows.  Returns the items consumed on every port."""
+        name, value[, complex vector]) inside the windows.  Returns the items consumed on every port; what a block
+        with outputs produced is appended to self.out / self.out_tags."""
         assert len(windows) == self.n_in
         nin = (ctypes.c_int * self.n_in)(*[len(w) for w in windows])
         ptrs = (ctypes.c_void_p * self.n_in)(*[w.ctypes.data for w in windows])
@@ -110,21 +123,51 @@ class StreamBlock:
                 recs[i].cvec = v.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
                 recs[i].cvec_len = len(v) // 2
         consumed = ctypes.c_int(0)
-        self._check(self.lib.gr80211_block_work(self.h, max(len(w) for w in windows), nin, ptrs, self.n_in, recs,
-                                                len(tags), ctypes.byref(consumed)), "work")
+        if self.n_out == 0:
+            self._check(self.lib.gr80211_block_work(self.h, max(len(w) for w in windows), nin, ptrs, self.n_in, recs,
+                                                    len(tags), ctypes.byref(consumed)), "work")
+            return consumed.value
+        bufs = [np.zeros(noutput_items, OUT_DTYPES[self.kind]) for _ in range(self.n_out)]
+        optrs = (ctypes.c_void_p * self.n_out)(*[b.ctypes.data for b in bufs])
+        cap = 4096
+        trecs = (Tag * cap)()
+        nt = ctypes.c_int(0)
+        produced = self._check(self.lib.gr80211_block_work_out(
+            self.h, noutput_items, nin, ptrs, self.n_in, recs, len(tags), optrs, self.n_out, trecs, cap, ctypes.byref(nt),
+            ctypes.byref(consumed)), "work_out")
+        for p in range(self.n_out):
+            self.out[p].append(bufs[p][:produced].copy())
+        for i in range(nt.value):
+            r = trecs[i]
+            vec = None
+            if r.cvec and r.cvec_len:
+                vec = np.ctypeslib.as_array(r.cvec, shape=(2 * r.cvec_len,)).view(np.complex64).copy()
+            self.out_tags.append((int(r.offset), TAG_KEYS[r.key], float(r.value), vec))
         return consumed.value
+
+    def drain(self, noutput_items=8192):
+        """Fetch what a block with outputs still holds (calls without input)."""
+        empty = [np.zeros(0, np.uint8 if (self.kind in (SIGNAL, SIGNAL2) and p == 0) else np.complex64)
+                 for p in range(self.n_in)]
+        guard = 0
+        while self.n_out and self.lib.gr80211_block_pending_output(self.h) > 0 and guard < 1 << 20:
+            self.work(empty, (), noutput_items)
+            guard += 1
+
+    def output(self, port=0):
+        return np.concatenate(self.out[port]) if self.out[port] else np.zeros(0, OUT_DTYPES[self.kind])
 
     def flush(self):
         self._check(self.lib.gr80211_block_flush(self.h), "flush")
 
-    def run(self, streams, tags=(), chunk=4096):
+    def run(self, streams, tags=(), chunk=4096, noutput_items=8192):
         streams = [np.ascontiguousarray(s) for s in streams]
         n = min(len(s) for s in streams)
         tags = sorted(tags, key=lambda t: (t[1], t[0]))
         at, idle = 0, 0
         while at < n:
             win = min(chunk, n - at)
-            got = self.work([s[at:at + win] for s in streams], [t for t in tags if at <= t[0] < at + win])
+            got = self.work([s[at:at + win] for s in streams], [t for t in tags if at <= t[0] < at + win], noutput_items)
             # tags of items not consumed are handed over again with the next window, like a scheduler's tag store
             at += got
             if got == 0:
@@ -135,4 +178,5 @@ class StreamBlock:
             else:
                 idle = 0
         self.flush()
+        self.drain(noutput_items)
         return self.msgs

@@ -11,9 +11,16 @@
  *   GR80211_BLOCK_RX2       ieee80211::signal2 -> demod2 -> decode: in {u8 sync, c64, c64} (lib/signal2_impl.cc:35-37)
  *   GR80211_BLOCK_CAPTURE   presiso -> trigger -> sync -> signal -> demod -> decode (examples/rx.grc): in {c64}
  *   GR80211_BLOCK_CAPTURE2  the same with two antennas (examples/rx2.grc): in {c64, c64}
+ *   GR80211_BLOCK_SIGNAL    ieee80211::signal alone (lib/signal_impl.cc:34-206): in {u8 sync, c64}, out {c64} with the
+ *                           tags cfo, snr, rssi, seq, mcs, len, nsamp, chan on a frame's first item
+ *   GR80211_BLOCK_SIGNAL2   ieee80211::signal2 (lib/signal2_impl.cc): in {u8 sync, c64, c64}, out {c64, c64}
+ *   GR80211_BLOCK_DEMOD     ieee80211::demod alone (lib/demod_impl.cc:59-342): in {c64} with those tags, out {f32 soft
+ *                           bits} with the tags decode reads (plus cfo, snr, rssi, sssnr0)
+ *   GR80211_BLOCK_DEMOD2    ieee80211::demod2 (lib/demod2_impl.cc:58-349): in {c64, c64}, out {f32}
  *
- * Every kind has no stream output; messages of port "out" are the blobs `decode` publishes
- * (lib/decode_impl.cc:512-516).  A block is driven by one thread at a time, like a GNU Radio block.
+ * The first five kinds have no stream output; messages of port "out" are the blobs `decode` publishes
+ * (lib/decode_impl.cc:512-516).  The others are driven with gr80211_block_work_out.  A block is driven by one
+ * thread at a time, like a GNU Radio block.
  */
 #ifndef GR80211_HOST_H
 #define GR80211_HOST_H
@@ -29,6 +36,10 @@ extern "C" {
 #define GR80211_BLOCK_RX2 2
 #define GR80211_BLOCK_CAPTURE 3
 #define GR80211_BLOCK_CAPTURE2 4
+#define GR80211_BLOCK_SIGNAL 5
+#define GR80211_BLOCK_SIGNAL2 6
+#define GR80211_BLOCK_DEMOD 7
+#define GR80211_BLOCK_DEMOD2 8
 
 /* tag keys (the pmt symbols of the reference's tags) */
 #define GR80211_TAG_RAD 0
@@ -42,6 +53,12 @@ extern "C" {
 #define GR80211_TAG_AMPDU 8
 #define GR80211_TAG_TRELLIS 9
 #define GR80211_TAG_MU2X1CHAN 10 /* c32vector of 128: cvec points at 256 floats, re/im interleaved */
+#define GR80211_TAG_CFO 11
+#define GR80211_TAG_SEQ 12
+#define GR80211_TAG_NSAMP 13
+#define GR80211_TAG_CHAN 14 /* c32vector of 64 */
+#define GR80211_TAG_SSSNR0 15
+#define GR80211_TAG_SSSNR1 16
 
 typedef struct {
     uint64_t offset; /* absolute item index on the port, like gr::tag_t::offset */
@@ -75,6 +92,18 @@ int gr80211_block_forecast(gr80211_block *b, int noutput_items, int *ninput_item
  */
 int gr80211_block_work(gr80211_block *b, int noutput_items, const int *ninput_items, const void *const *input_items,
                        int n_inputs, const gr80211_tag *tags, int n_tags, int *consumed);
+/*
+ * general_work of a block with stream outputs.  output_items: one buffer per output port with room for
+ * noutput_items items; tags_out receives the tags of the items produced (at most cap_tags_out; their cvec pointers
+ * stay valid until the block's next call).  Returns the items produced on every output port.  A block may hold
+ * produced items back until there is room: gr80211_block_pending_output tells how many, and a call without
+ * input (ninput_items all 0) fetches them.
+ */
+int gr80211_block_n_outputs(const gr80211_block *b);
+int gr80211_block_work_out(gr80211_block *b, int noutput_items, const int *ninput_items, const void *const *input_items,
+                           int n_inputs, const gr80211_tag *tags, int n_tags, void *const *output_items, int n_outputs,
+                           gr80211_tag *tags_out, int cap_tags_out, int *n_tags_out, int *consumed);
+long long gr80211_block_pending_output(const gr80211_block *b);
 /* End of stream: decode what is buffered.  0 on success. */
 int gr80211_block_flush(gr80211_block *b);
 /* Text of the block's last error; with b == NULL, why the calling thread's last gr80211_block_create returned NULL. */

@@ -294,3 +294,84 @@ def test_streaming_abi_decode_block(pkg, rxctx, oracle):
         assert b.forecast(1000) == [1160]
         got = b.run([np.concatenate(parts).astype(np.float32)], tags, 1500)
     assert got == want
+
+
+@pytest.mark.parametrize("two,chunk,nout,batch", [(False, 4096, 8192, 1000), (False, 777, 500, 2), (True, 3000, 4096, 3)])
+def test_streaming_abi_signal_demod_decode_chain(pkg, oracle, two, chunk, nout, batch):
+    """The three blocks of the reference's flowgraph as three blocks here, each a drop-in for its own: signal's
+    items and tags go into demod, demod's soft bits and tags into decode; the messages equal the fused block's and
+    the oracle's.  Windows and output buffers are small, so frames straddle calls in every block."""
+    from importlib import import_module
+    stream = import_module("fork-gr-ieee80211_amd.stream")
+    if two:
+        rng = np.random.default_rng(9)
+        parts, triggers, pos = [], [], 0
+        for f in [f for f in golden_frames() if f["nss"] == 2]:
+            r = (H22 @ f["iq"]).astype(np.complex64)
+            parts.append(r)
+            triggers.append((pos + f["sync_idx"], f["rad"]))
+            pos += r.shape[1]
+        iq = np.concatenate(parts, axis=1)
+        iq = (iq + 0.001 * (rng.standard_normal(iq.shape) + 1j * rng.standard_normal(iq.shape))).astype(np.complex64)
+        ants = [iq[0], iq[1]]
+    else:
+        iq0, triggers, frames = siso_stream(0.002, 6)
+        ants = [iq0]
+    want, n_frames = model_chain(oracle, ants[0], ants[1] if two else None, triggers)
+    sync, tags = sync_stream(len(ants[0]), triggers)
+    with stream.StreamBlock(stream.SIGNAL2 if two else stream.SIGNAL, batch) as sg:
+        sg.run([sync] + ants, tags, chunk, nout)
+        sig_items = [sg.output(p) for p in range(len(ants))]
+        sig_tags = sg.out_tags
+    # signal: eight tags per frame on its first item, nsamp + 320 items per frame
+    firsts = sorted(set(t[0] for t in sig_tags))
+    assert len(firsts) == n_frames and len(sig_tags) == 8 * n_frames
+    nsamp = [int(t[2]) for t in sig_tags if t[1] == "nsamp"]
+    assert firsts == [int(v) for v in np.concatenate([[0], np.cumsum(np.array(nsamp) + 320)])[:-1]]
+    assert len(sig_items[0]) == sum(nsamp) + 320 * n_frames
+    assert [int(t[2]) for t in sig_tags if t[1] == "seq"] == list(range(1, n_frames + 1))
+    assert all(t[3] is not None and len(t[3]) == 64 for t in sig_tags if t[1] == "chan")
+    with stream.StreamBlock(stream.DEMOD2 if two else stream.DEMOD, batch) as dm:
+        dm.run(sig_items, [(t[0], 0, t[1], t[2], t[3]) for t in sig_tags], chunk, nout)
+        llr = dm.output(0)
+        llr_tags = dm.out_tags
+    totals = [int(t[2]) for t in llr_tags if t[1] == "total"]
+    assert len(llr) == sum(totals)
+    with stream.StreamBlock(stream.DECODE, batch) as dc:
+        got = dc.run([llr], [(t[0], 0, t[1], t[2], t[3]) for t in llr_tags if t[1] in stream.TAG_KEYS[:11]], chunk)
+    assert got == want
+
+
+def test_streaming_abi_chain_with_sounding_frame_and_mu(pkg, oracle):
+    """A sounding NDP between data frames through signal -> demod -> decode: demod passes its two VHT-LTF windows on
+    in the mu2x1chan tag with 1024 empty items and decode publishes the channel message; a two-user frame with the
+    demod block set to the second user's position gives that user's PSDU."""
+    from importlib import import_module
+    from util import golden_mu, golden_ndp
+    stream = import_module("fork-gr-ieee80211_amd.stream")
+    g = golden_ndp()
+    mu = golden_mu()
+    frames = [f for f in golden_frames() if f["nss"] == 1][:2]
+    for mu_pos in (0, 1):
+        parts = [frames[0]["iq"][0], g["iq"][0], np.asarray(mu["iq"][mu_pos], np.complex64), frames[1]["iq"][0],
+                 np.zeros(300, np.complex64)]
+        at = np.cumsum([0] + [len(p) for p in parts])
+        triggers = [(int(at[0]) + frames[0]["sync_idx"], frames[0]["rad"]), (int(at[1]) + g["sync_idx"], 0.0),
+                    (int(at[2]) + int(mu["sync_idx"]), 0.0), (int(at[3]) + frames[1]["sync_idx"], frames[1]["rad"])]
+        iq0 = np.concatenate(parts).astype(np.complex64)
+        sync, tags = sync_stream(len(iq0), triggers)
+        with stream.StreamBlock(stream.RX, 8) as b:
+            b.set_option(stream.OPT_MU_POS, mu_pos)
+            want = list(b.run([sync, iq0], tags, 1500))
+        assert len(want) == 4 and len(want[1]) == 1027 and want[1][0] == 20 and want[2][3:-1] == mu["mpdus"][mu_pos]
+        with stream.StreamBlock(stream.SIGNAL, 8) as sg:
+            sg.run([sync, iq0], tags, 1500, 2000)
+            items, stags = sg.output(0), sg.out_tags
+        with stream.StreamBlock(stream.DEMOD, 8) as dm:
+            dm.set_option(stream.OPT_MU_POS, mu_pos)
+            dm.run([items], [(t[0], 0, t[1], t[2], t[3]) for t in stags], 1500, 2000)
+            llr, ltags = dm.output(0), dm.out_tags
+        assert sum(1 for t in ltags if t[1] == "mu2x1chan" and t[3] is not None and len(t[3]) == 128) == 1
+        with stream.StreamBlock(stream.DECODE, 8) as dc:
+            got = dc.run([llr], [(t[0], 0, t[1], t[2], t[3]) for t in ltags if t[1] in stream.TAG_KEYS[:11]], 1500)
+        assert got == want
