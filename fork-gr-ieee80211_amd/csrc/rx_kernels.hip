@@ -1713,13 +1713,15 @@ int read_timeline(unsigned long long *dst, int n_groups)
 }
 #endif
 
-// Four groups per workgroup, one per wave: the hardware spreads the waves of a workgroup over the four SIMDs of a
-// CU, so a CU holds either one wave per SIMD or two, never two on one SIMD beside an idle one.  The waves share
-// nothing and never meet at a barrier (their trellises differ in length).
+// WAVES groups per workgroup, one per wave; the waves share nothing and never meet at a barrier (their trellises
+// differ in length).  Four: the hardware spreads the waves of a workgroup over the four SIMDs of a CU, which a batch
+// of at most one group per SIMD needs (one-wave workgroups get stacked two to a SIMD beside idle SIMDs).  One: for
+// larger batches, where single waves spread more evenly over the CUs than whole workgroups of four (measured at
+// 1563 groups: 12.0 against 12.5 ms).
 constexpr int DEC_WAVES = 4;
 
-template <bool TWO_TILES>
-__global__ __launch_bounds__(64 * DEC_WAVES) void k_decode(const float *__restrict__ llr, const gr80211_frame_info *__restrict__ info,
+template <bool TWO_TILES, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void k_decode(const float *__restrict__ llr, const gr80211_frame_info *__restrict__ info,
                                                const int32_t *__restrict__ slot_frame,
                                                const GroupInfo *__restrict__ groups, int n_groups,
                                                uint32_t *__restrict__ dec, uint32_t *__restrict__ bitsw,
@@ -1728,7 +1730,7 @@ __global__ __launch_bounds__(64 * DEC_WAVES) void k_decode(const float *__restri
                                                int strict)
 {
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int g = blockIdx.x * DEC_WAVES + wv;
+    const int g = blockIdx.x * WAVES + wv;
     if (g >= n_groups) return;
     const int lane = threadIdx.x & 63;
 #ifdef GR80211_TIMELINE
@@ -1737,7 +1739,7 @@ __global__ __launch_bounds__(64 * DEC_WAVES) void k_decode(const float *__restri
         g_timeline[4 * g + 3] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));  // HW_ID
     }
 #endif
-    __shared__ float tiles[DEC_WAVES][(TWO_TILES ? 2 : 1) * 64 * TILE_STRIDE];
+    __shared__ float tiles[WAVES][(TWO_TILES ? 2 : 1) * 64 * TILE_STRIDE];
     float *tile = tiles[wv];
     const GroupInfo gi = groups[g];
     const int fr = slot_frame[g * 64 + lane];
@@ -1926,17 +1928,17 @@ void launch_decode(const float *llr, const gr80211_frame_info *info, const int32
                    const GroupInfo *groups, int n_groups, uint32_t *dec, uint32_t *bitsw, uint8_t *out, int out_stride,
                    int32_t *out_len, int32_t *n_pdu, uint8_t *bits_out, int bits_stride, int strict, hipStream_t s)
 {
-    const dim3 grid((n_groups + DEC_WAVES - 1) / DEC_WAVES), block(64 * DEC_WAVES);
     // A batch of at most one group per SIMD runs fastest with exactly one wave on every SIMD (a lone wave finishes
-    // its trellis in three quarters of the time a paired one needs).  The two-tile form needs 130 KB of LDS per
-    // workgroup, so a CU takes one workgroup and 256 workgroups cover the 256 CUs; the one-tile form (65 KB) lets two
-    // workgroups share a CU, two waves per SIMD.
+    // its trellis in three quarters of the time a paired one needs): workgroups of four waves with two LDS tiles each,
+    // 130 KB per workgroup, so a CU takes one workgroup and 256 workgroups cover the 256 CUs.  Larger batches run one
+    // group per workgroup with one tile (16 KB), two waves per SIMD.
     if (n_groups <= 1024)
-        hipLaunchKernelGGL(k_decode<true>, grid, block, 0, s, llr, info, slot_frame, groups, n_groups, dec, bitsw, out,
-                           out_stride, out_len, n_pdu, bits_out, bits_stride, strict);
+        hipLaunchKernelGGL((k_decode<true, DEC_WAVES>), dim3((n_groups + DEC_WAVES - 1) / DEC_WAVES), dim3(64 * DEC_WAVES), 0, s,
+                           llr, info, slot_frame, groups, n_groups, dec, bitsw, out, out_stride, out_len, n_pdu, bits_out,
+                           bits_stride, strict);
     else
-        hipLaunchKernelGGL(k_decode<false>, grid, block, 0, s, llr, info, slot_frame, groups, n_groups, dec, bitsw, out,
-                           out_stride, out_len, n_pdu, bits_out, bits_stride, strict);
+        hipLaunchKernelGGL((k_decode<false, 1>), dim3(n_groups), dim3(64), 0, s, llr, info, slot_frame, groups, n_groups, dec,
+                           bitsw, out, out_stride, out_len, n_pdu, bits_out, bits_stride, strict);
 }
 void launch_ndp_emit(const void *iq0, uint64_t arena_len, const gr80211_frame_desc *desc, int n,
                      const gr80211_frame_info *info, uint8_t *out, int out_stride, int32_t *out_len, int32_t *n_pdu,
