@@ -1730,8 +1730,11 @@ __global__ __launch_bounds__(64 * WAVES) void k_decode(const float *__restrict__
                                                int strict)
 {
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int g = blockIdx.x * WAVES + wv;
-    if (g >= n_groups) return;
+    const int g0 = blockIdx.x * WAVES + wv;
+    if (g0 >= n_groups) return;
+    // the scheduler numbers the groups of a code rate by rising trellis length; workgroups start in index order, so
+    // the numbering is walked backwards and the longest trellises start first (a mixed batch ends 6 % sooner)
+    const int g = n_groups - 1 - g0;
     const int lane = threadIdx.x & 63;
 #ifdef GR80211_TIMELINE
     if (lane == 0 && g < 8192) {
