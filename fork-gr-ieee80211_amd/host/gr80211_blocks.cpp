@@ -659,6 +659,12 @@ signal::signal(int n_rx, int batch_frames, int device)
 {
 }
 
+void signal::forecast(int noutput_items, gr_vector_int &ninput_items_required)
+{
+    // items held back for lack of room need no input to leave
+    for (int &v : ninput_items_required) v = d_out0.pending() ? 0 : noutput_items;
+}
+
 int signal::general_work(int noutput_items, gr_vector_int &ninput_items, gr_vector_const_void_star &input_items,
                          gr_vector_void_star &output_items)
 {
@@ -742,7 +748,8 @@ demod::demod(int n_rx, int mupos, int batch_frames, int device)
 
 void demod::forecast(int noutput_items, gr_vector_int &ninput_items_required)
 {
-    for (int &v : ninput_items_required) v = noutput_items;  // lib/demod_impl.cc:53-57
+    // lib/demod_impl.cc:53-57; soft bits held back for lack of room need no input to leave
+    for (int &v : ninput_items_required) v = d_out.pending() ? 0 : noutput_items;
 }
 
 int demod::general_work(int noutput_items, gr_vector_int &ninput_items, gr_vector_const_void_star &input_items,

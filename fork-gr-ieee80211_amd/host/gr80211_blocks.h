@@ -267,6 +267,7 @@ class signal : public rx
 public:
     typedef std::shared_ptr<signal> sptr;
     static sptr make(int n_rx = 1, int batch_frames = 4096, int device = 0);
+    void forecast(int noutput_items, gr_vector_int &ninput_items_required) override;
     int general_work(int noutput_items, gr_vector_int &ninput_items, gr_vector_const_void_star &input_items,
                      gr_vector_void_star &output_items) override;
     size_t pending_output() const { return d_out0.pending(); }
