@@ -14,6 +14,7 @@ const int LSIG_SPAN = 224;       // samples from the trigger to the end of L-SIG
 const int F_VHT_CHAN = 20;       // format byte of the sounding channel message (lib/cloud80211phy.h:40)
 const int LSIG_FAIL_SKIP = 80;   // samples dropped after a failed L-SIG check (lib/signal_impl.cc:156-160)
 const int OUT_STRIDE = 4352;     // room for the PDUs of one frame: 4095 bytes + headers of a few subframes
+const size_t OUT_QUEUE_LIMIT = (size_t)1 << 24;  // produced items a block holds before it stops taking input
 const long DEFAULT_TAG = 99999;  // value `decode` assumes for a missing tag (lib/decode_impl.cc:77-83)
 
 double tag_value(const std::vector<tag_t> &tags, const char *key, double dflt)
@@ -668,7 +669,8 @@ void signal::forecast(int noutput_items, gr_vector_int &ninput_items_required)
 int signal::general_work(int noutput_items, gr_vector_int &ninput_items, gr_vector_const_void_star &input_items,
                          gr_vector_void_star &output_items)
 {
-    const int n = take_input(ninput_items, input_items);
+    // input is only taken while the items already produced find room downstream
+    const int n = d_out0.pending() > OUT_QUEUE_LIMIT ? 0 : take_input(ninput_items, input_items);
     consume_each(n < 0 ? 0 : n);
     if ((int)output_items.size() < d_nrx) return 0;
     std::vector<tag_t> tags;
@@ -757,6 +759,7 @@ int demod::general_work(int noutput_items, gr_vector_int &ninput_items, gr_vecto
 {
     int n = ninput_items[0];
     if (d_nrx == 2) n = std::min(n, ninput_items[1]);
+    if (d_out.pending() > OUT_QUEUE_LIMIT) n = 0;  // input is only taken while the soft bits produced find room
     int used = 0;
     std::vector<tag_t> tags;
     while (used < n) {
