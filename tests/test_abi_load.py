@@ -25,6 +25,11 @@ def test_struct_sizes_match_header(pkg):
     assert ctypes.sizeof(pkg.rx.FrameDesc) == 32
     assert ctypes.sizeof(pkg.rx.FrameInfo) == 112
     assert ctypes.sizeof(pkg.rx.DecDesc) == 40
+    assert pkg.rx.SIG_DESC_DTYPE.itemsize == 48 and pkg.rx.TX_DESC_DTYPE.itemsize == 40 and pkg.rx.TX_MU_DESC_DTYPE.itemsize == 56
+    # the C compiler lays gr80211_sig_desc out as the binding does: 8-byte offset first, 44 bytes of fields, padded to 48
+    names = [n for n in pkg.rx.SIG_DESC_DTYPE.names]
+    assert names[:10] == ["off", "n_avail", "mcs", "len", "nsamp", "cfo", "snr", "rssi", "mu_pos", "reserved"]
+    assert pkg.rx.SIG_DESC_DTYPE.fields["mu_pos"][1] == 36
 
 
 def test_version_and_tables(pkg):
