@@ -11,6 +11,11 @@
 
 using namespace gr80211;
 
+// the record layouts are part of the C-ABI: bindings in other languages restate them
+static_assert(sizeof(gr80211_frame_desc) == 32 && sizeof(gr80211_frame_info) == 112 && sizeof(gr80211_dec_desc) == 40 &&
+                  sizeof(gr80211_sig_desc) == 48 && sizeof(gr80211_tx_desc) == 40 && sizeof(gr80211_tx_mu_desc) == 56,
+              "C-ABI record sizes");
+
 namespace {
 
 struct Buf {
