@@ -3,6 +3,9 @@
 //
 //   gr80211_pump rx <n_rx> <chunk> <batch> <triggers.txt> <iq0.bin> [iq1.bin]
 //       triggers.txt: one "pos rad snr rssi" line per tagged sync byte; iq*.bin: interleaved float32 I/Q
+//   gr80211_pump chain <n_rx> <chunk> <batch> <triggers.txt> <iq0.bin> [iq1.bin]
+//       the same input through three blocks, signal -> demod -> decode, joined by buffers of <chunk> items the
+//       way a flowgraph joins them
 //   gr80211_pump capture <n_rx> <chunk> <iq0.bin> [iq1.bin]
 //       no sync stream: frame detection runs on the GPU as well
 //   gr80211_pump decode <chunk> <batch> <tags.txt> <llr.bin>
@@ -11,6 +14,7 @@
 // Output: "PDU <hex of the message blob>" per message (not with GR80211_PUMP_QUIET=1 in the environment), then
 // "STAT ..." counters and the seconds spent between the first general_work call and the end of flush().
 // Exit code 0 on success.
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -85,6 +89,67 @@ static bool pump(block &b, const std::vector<const char *> &ports, const std::ve
     return true;
 }
 
+// A stream between two blocks: items and their tags (absolute offsets).
+struct link {
+    size_t item;
+    std::vector<char> buf;   // items written by the producer; the reader is at byte `head`
+    size_t head = 0;
+    uint64_t base = 0;       // absolute index of the item at `head`
+    std::vector<tag_t> tags; // in offset order; those before tag_head have been passed
+    size_t tag_head = 0;
+    explicit link(size_t it) : item(it) {}
+    size_t items() const { return (buf.size() - head) / item; }
+    const char *data() const { return buf.data() + head; }
+    void consume(size_t n)
+    {
+        head += n * item;
+        base += n;
+        while (tag_head < tags.size() && tags[tag_head].offset < base) tag_head++;
+        if (head > ((size_t)1 << 24) && head * 2 > buf.size()) {  // drop what has been read
+            buf.erase(buf.begin(), buf.begin() + (long)head);
+            head = 0;
+            tags.erase(tags.begin(), tags.begin() + (long)tag_head);
+            tag_head = 0;
+        }
+    }
+};
+
+// One general_work call of `b`: reads from `in` (all ports advance together), appends what it produces to `out`.
+static bool step(block &b, std::vector<link *> in, std::vector<link *> out, int chunk, bool &progress)
+{
+    size_t avail = in.empty() ? 0 : in[0]->items();
+    for (link *l : in) avail = std::min(avail, l->items());
+    const int win = (int)std::min<size_t>(avail, (size_t)chunk);
+    gr_vector_int nin(in.size(), win);
+    gr_vector_const_void_star ip(in.size());
+    b.clear_item_tags_in();
+    for (size_t p = 0; p < in.size(); p++) {
+        ip[p] = in[p]->data();
+        for (size_t k = in[p]->tag_head; k < in[p]->tags.size() && in[p]->tags[k].offset < in[p]->base + (uint64_t)win; k++)
+            b.add_item_tag_in((int)p, in[p]->tags[k]);
+    }
+    std::vector<std::vector<char>> ob(out.size());
+    gr_vector_void_star op(out.size());
+    for (size_t p = 0; p < out.size(); p++) {
+        ob[p].resize((size_t)chunk * out[p]->item);
+        op[p] = ob[p].data();
+    }
+    const int produced = b.general_work(chunk, nin, ip, op);
+    const int used = b.consumed();
+    for (size_t p = 0; p < out.size(); p++) {
+        out[p]->buf.insert(out[p]->buf.end(), ob[p].begin(), ob[p].begin() + (long)((size_t)produced * out[p]->item));
+        for (tag_t &t : b.take_output_tags((int)p)) out[p]->tags.push_back(std::move(t));
+    }
+    b.commit(produced);
+    if (!b.last_error().empty()) {
+        fprintf(stderr, "block error: %s\n", b.last_error().c_str());
+        return false;
+    }
+    for (link *l : in) l->consume((size_t)used);
+    progress = progress || used > 0 || produced > 0;
+    return true;
+}
+
 int main(int argc, char **argv)
 {
     if (const char *q = getenv("GR80211_PUMP_QUIET")) g_quiet = q[0] == '1';
@@ -123,6 +188,68 @@ int main(int argc, char **argv)
         const bool ok = pump(*b, ports, isz, n, chunk);
         printf("STAT triggers=%llu frames=%llu pdus=%llu\n", (unsigned long long)b->triggers_seen(),
                (unsigned long long)b->frames_decoded(), (unsigned long long)b->pdus_published());
+        printf("TIME items=%zu seconds=%.6f\n", n, g_seconds);
+        return ok ? 0 : 1;
+    }
+    if (argc >= 7 && !strcmp(argv[1], "chain")) {
+        const int n_rx = atoi(argv[2]), chunk = atoi(argv[3]), batch = atoi(argv[4]);
+        std::vector<char> iq0, iq1;
+        if (!read_file(argv[6], iq0) || (n_rx == 2 && (argc < 8 || !read_file(argv[7], iq1)))) {
+            fprintf(stderr, "cannot read IQ file\n");
+            return 2;
+        }
+        size_t n = iq0.size() / 8;
+        if (n_rx == 2) n = std::min(n, iq1.size() / 8);
+        signal::sptr sg = signal::make(n_rx, batch, 0);
+        demod::sptr dm = demod::make(n_rx, 0, 2, batch, 0);
+        decode::sptr dc = decode::make(false, batch, 0);
+        dc->set_msg_handler(on_msg);
+        link l_sync(1), l_a(8), l_b(8), l_s0(8), l_s1(8), l_llr(4);
+        l_sync.buf.assign(n, 0);
+        l_a.buf.assign(iq0.begin(), iq0.begin() + (long)(n * 8));
+        if (n_rx == 2) l_b.buf.assign(iq1.begin(), iq1.begin() + (long)(n * 8));
+        FILE *f = fopen(argv[5], "r");
+        if (!f) return 2;
+        unsigned long long pos;
+        float rad, snr, rssi;
+        std::vector<tag_t> trig;
+        while (fscanf(f, "%llu %f %f %f", &pos, &rad, &snr, &rssi) == 4) {
+            if (pos >= n) continue;
+            l_sync.buf[pos] = 1;
+            tag_t t;
+            t.offset = pos;
+            t.key = "rad"; t.value = rad; trig.push_back(t);
+            t.key = "snr"; t.value = snr; trig.push_back(t);
+            t.key = "rssi"; t.value = rssi; trig.push_back(t);
+        }
+        fclose(f);
+        std::stable_sort(trig.begin(), trig.end(), [](const tag_t &a, const tag_t &b) { return a.offset < b.offset; });
+        l_sync.tags = trig;
+        std::vector<link *> in_sg = {&l_sync, &l_a}, out_sg = {&l_s0}, in_dm = {&l_s0};
+        if (n_rx == 2) {
+            in_sg.push_back(&l_b);
+            out_sg.push_back(&l_s1);
+            in_dm.push_back(&l_s1);
+        }
+        const auto t0 = std::chrono::steady_clock::now();
+        bool ok = true, flushed_sg = false, flushed_dm = false;
+        for (int idle = 0; ok && idle < 4;) {
+            bool progress = false;
+            ok = step(*sg, in_sg, out_sg, chunk, progress) && step(*dm, in_dm, {&l_llr}, chunk, progress) &&
+                 step(*dc, {&l_llr}, {}, chunk, progress);
+            if (progress) {
+                idle = 0;
+                continue;
+            }
+            // nothing moves any more: end of stream for the next block that still buffers frames
+            if (!flushed_sg) { ok = sg->flush(); flushed_sg = true; continue; }
+            if (!flushed_dm) { ok = dm->flush(); flushed_dm = true; continue; }
+            idle++;
+        }
+        ok = ok && dc->flush();
+        g_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        printf("STAT triggers=%llu frames=%llu pdus=%llu\n", (unsigned long long)sg->triggers_seen(),
+               (unsigned long long)sg->frames_decoded(), (unsigned long long)dc->pdus_published());
         printf("TIME items=%zu seconds=%.6f\n", n, g_seconds);
         return ok ? 0 : 1;
     }
@@ -181,6 +308,7 @@ int main(int argc, char **argv)
         return ok ? 0 : 1;
     }
     fprintf(stderr, "usage: gr80211_pump rx <n_rx> <chunk> <batch> <triggers.txt> <iq0.bin> [iq1.bin]\n"
+                    "       gr80211_pump chain <n_rx> <chunk> <batch> <triggers.txt> <iq0.bin> [iq1.bin]\n"
                     "       gr80211_pump capture <n_rx> <chunk> <iq0.bin> [iq1.bin]\n"
                     "       gr80211_pump decode <chunk> <batch> <tags.txt> <llr.bin>\n");
     return 2;

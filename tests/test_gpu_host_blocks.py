@@ -395,3 +395,15 @@ def test_instance_and_empty_run_of_every_block_kind(pkg):
             assert b.work([np.zeros(100, d) for d in dt]) == 100   # untagged items are passed over
             b.flush()
             assert b.msgs == [] and all(len(b.output(p)) == 0 for p in range(n_out))
+
+
+@pytest.mark.parametrize("chunk,batch", [(4096, 1000), (777, 2)])
+def test_pump_chain_of_three_blocks(tmp_path, oracle, chunk, batch):
+    """The command-line scheduler joins signal -> demod -> decode by buffers of `chunk` items (C++ only, no Python
+    between the blocks): same messages as the fused block."""
+    iq0, triggers, frames = siso_stream(0.002, 6)
+    want, n_frames = model_chain(oracle, iq0, None, triggers)
+    tf, files = write_stream(tmp_path, iq0, None, triggers)
+    got, stat = run_pump(["chain", 1, chunk, batch, tf] + files)
+    assert got == want
+    assert "frames=%d " % n_frames in stat + " ", stat

@@ -64,6 +64,7 @@ def main():
     print("%d VHT MCS8 frames, %d samples per antenna, %.0f MB of IQ" % (n, ns, ns * 8 / 1e6), flush=True)
     for chunk, batch in ((8192, 4096), (65536, 4096), (65536, 16384), (1 << 20, 16384)):
         run(["rx", 1, chunk, batch, f_tr, f_iq], ns, "rx      window %7d batch %5d" % (chunk, batch))
+    run(["chain", 1, 65536, 4096, f_tr, f_iq], ns, "signal->demod->decode, 65536/4096")
     run(["capture", 1, 65536, f_iq], ns, "capture window   65536")
     for chunk, batch in ((65536, 4096), (1 << 20, 16384)):
         run(["decode", chunk, batch, f_tg, f_llr], ns, "decode  window %7d batch %5d" % (chunk, batch))
