@@ -1350,8 +1350,10 @@ __device__ __forceinline__ void two_periods(float (&A)[64], float (&B)[64], cons
 // (global_load_lds_dword: lane l of the wave writes tile[row][l]), so all 64 are in flight together and cost no
 // VGPRs while the 128 path-metric registers are live.  Columns past a frame's last soft bit are clamped to it:
 // they only feed trellis steps after that frame's end.
+typedef __attribute__((address_space(3))) float lds_float;
+
 __device__ __forceinline__ void load_tile(const float *__restrict__ llr, unsigned long long mybase, int myn, int c0,
-                                          float *tile)
+                                          lds_float *tile)
 {
 #pragma unroll
     for (int r = 0; r < 64; r++) {
@@ -1365,6 +1367,34 @@ __device__ __forceinline__ void load_tile(const float *__restrict__ llr, unsigne
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                          (__attribute__((address_space(3))) void *)(tile + r * TILE_STRIDE), 4, 0, 0);
     }
+}
+
+// The same for a chunk that lies inside every frame of the group (all chunks but the last few): no clamping, so a
+// row's address is a wave-uniform base plus the lane's column, which costs a third of the instructions per row.
+// Lanes without a frame read soft bits of some other frame at that column; nothing uses them.
+__device__ __forceinline__ void load_tile_inside(const float *__restrict__ llr, unsigned long long mybase, int col0, int lane,
+                                                 lds_float *tile)
+{
+    // every lane's row address in bytes; the row's own comes out of it with two v_readlane
+    const unsigned long long mine = (unsigned long long)(llr + mybase);
+    const unsigned long long step = (unsigned long long)col0 * sizeof(float);
+#pragma unroll
+    for (int r = 0; r < 64; r++) {
+        const unsigned lo = __builtin_amdgcn_readlane((int)(mine & 0xffffffffull), r);
+        const unsigned hi = __builtin_amdgcn_readlane((int)(mine >> 32), r);
+        const float *rowp = (const float *)((((unsigned long long)hi << 32) | lo) + step);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(rowp + lane),
+                                         (__attribute__((address_space(3))) void *)(tile + r * TILE_STRIDE), 4, 0, 0);
+    }
+}
+
+// The tile whose first column is col0: without clamping where every frame of the group (the shortest has `least`
+// soft bits) reaches past the tile's 64 columns.
+__device__ __forceinline__ void fetch_tile(const float *__restrict__ llr, unsigned long long mybase, int myn, int least,
+                                           int col0, int lane, lds_float *tile)
+{
+    if (col0 + 64 <= least) load_tile_inside(llr, mybase, col0, lane, tile);
+    else load_tile(llr, mybase, myn, col0 + lane, tile);
 }
 
 // Forward pass of one group.  TWO_TILES: the wave has room for two tiles in LDS (a batch of at most one group per
@@ -1389,7 +1419,13 @@ __device__ __forceinline__ void viterbi_group(const float *__restrict__ llr, uns
     // waves therefore trade priority in time slices of 2^GR80211_PRIO_SHIFT ticks of the 100-MHz clock (both
     // read the same clock; the wave slot number tells them apart), so that both stay paired until the end.
     const unsigned slot_parity = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (3 << 11)) & 1u;  // HW_ID.wave_id
-    if (TWO_TILES) load_tile(llr, mybase, myn, lane, tile);
+    // soft bits the shortest frame of the group has: chunks below that mark need no clamping (lanes without a
+    // frame do not count)
+    int least = myn > 0 ? myn : 0x7fffffff;
+    for (int d = 32; d > 0; d >>= 1) least = min(least, __shfl_xor(least, d));
+    least = __builtin_amdgcn_readfirstlane(least);
+    lds_float *lt = (lds_float *)tile;  // the wave's tile(s), as the LDS addresses the DMA loads take
+    if (TWO_TILES) fetch_tile(llr, mybase, myn, least, 0, lane, lt);
     for (int ch = 0; ch < nchunks; ch++) {
         float *cur = tile;
         if (TWO_TILES) {
@@ -1400,7 +1436,7 @@ __device__ __forceinline__ void viterbi_group(const float *__restrict__ llr, uns
             else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(STEPS / 2) : "memory");
             // the other tile's last readers were the steps of the previous chunk: their values have arrived
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (ch + 1 < nchunks) load_tile(llr, mybase, myn, (ch + 1) * CH + lane, tile + ((ch + 1) & 1) * (64 * TILE_STRIDE));
+            if (ch + 1 < nchunks) fetch_tile(llr, mybase, myn, least, (ch + 1) * CH, lane, lt + ((ch + 1) & 1) * (64 * TILE_STRIDE));
         } else {
             if ((((unsigned)(__builtin_amdgcn_s_memrealtime() >> GR80211_PRIO_SHIFT)) ^ slot_parity) & 1u)
                 __builtin_amdgcn_s_setprio(2);
@@ -1409,7 +1445,7 @@ __device__ __forceinline__ void viterbi_group(const float *__restrict__ llr, uns
             // the tile belongs to this wave alone: its reads of the previous chunk have returned (their values were
             // used), so the loads below may overwrite it
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            load_tile(llr, mybase, myn, ch * CH + lane, tile);
+            fetch_tile(llr, mybase, myn, least, ch * CH, lane, lt);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __builtin_amdgcn_wave_barrier();
