@@ -143,22 +143,42 @@ __device__ __forceinline__ void viterbi_split(const float *__restrict__ llr, uns
 #pragma unroll
     for (int i = 0; i < 16; i++) A[i] = (16 * WI + i) == 0 ? 0.0f : NEG_INIT;
     const float *row = tile + lane * TILE_STRIDE;
+    typedef __attribute__((address_space(3))) float lds_float;
+    lds_float *lt = (lds_float *)tile;
+    // soft bits the shortest frame of the group has (lanes without a frame do not count): tiles below that mark
+    // need no clamping, and a row's address is a wave-uniform base plus the lane's column
+    int least = myn > 0 ? myn : 0x7fffffff;
+    for (int d = 32; d > 0; d >>= 1) least = min(least, __shfl_xor(least, d));
+    least = __builtin_amdgcn_readfirstlane(least);
+    const unsigned long long mine = (unsigned long long)(llr + mybase);  // this lane's row address in bytes
     int flip = 0;
     for (int ch = 0; ch < nchunks; ch++) {
         __syncthreads();
         const int c0 = ch * CH + lane;
         // the 64 x 64 soft-bit tile is shared; each wave fetches every fourth row (LDS-DMA, one row per load)
+        if (ch * CH + 64 <= least) {
+            const unsigned long long step = (unsigned long long)(ch * CH) * sizeof(float);
 #pragma unroll
-        for (int r = WI; r < 64; r += 4) {
-            const unsigned lo = __builtin_amdgcn_readlane((int)(mybase & 0xffffffffull), r);
-            const unsigned hi = __builtin_amdgcn_readlane((int)(mybase >> 32), r);
-            const int nr = __builtin_amdgcn_readlane(myn, r);
-            const unsigned long long base = ((unsigned long long)hi << 32) | lo;
-            int idx = c0 < nr ? c0 : nr - 1;
-            idx = idx < 0 ? 0 : idx;
-            const float *src = llr + base + (unsigned long long)idx;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                             (__attribute__((address_space(3))) void *)(tile + r * TILE_STRIDE), 4, 0, 0);
+            for (int r = WI; r < 64; r += 4) {
+                const unsigned lo = __builtin_amdgcn_readlane((int)(mine & 0xffffffffull), r);
+                const unsigned hi = __builtin_amdgcn_readlane((int)(mine >> 32), r);
+                const float *rowp = (const float *)((((unsigned long long)hi << 32) | lo) + step);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(rowp + lane),
+                                                 (__attribute__((address_space(3))) void *)(lt + r * TILE_STRIDE), 4, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int r = WI; r < 64; r += 4) {
+                const unsigned lo = __builtin_amdgcn_readlane((int)(mybase & 0xffffffffull), r);
+                const unsigned hi = __builtin_amdgcn_readlane((int)(mybase >> 32), r);
+                const int nr = __builtin_amdgcn_readlane(myn, r);
+                const unsigned long long base = ((unsigned long long)hi << 32) | lo;
+                int idx = c0 < nr ? c0 : nr - 1;
+                idx = idx < 0 ? 0 : idx;
+                const float *src = llr + base + (unsigned long long)idx;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                                 (__attribute__((address_space(3))) void *)(lt + r * TILE_STRIDE), 4, 0, 0);
+            }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
