@@ -257,10 +257,12 @@ def ampdu_vht(mpdus, eof=None):
     return out
 
 
-def gen_frame(fmt, mcs, nss, mpdu, scrambler=93, n_mpdu_list=None, ht_aggregate=False):
+def gen_frame(fmt, mcs, nss, mpdu, scrambler=93, n_mpdu_list=None, ht_aggregate=False, short_gi=False):
     """Baseband frame(s): returns (array [nss][N] complex128, Mod).  For VHT `mpdu` is wrapped into a
     single-subframe A-MPDU (pass n_mpdu_list=[m0, m1, ...] for several subframes).  ht_aggregate: HT PSDU =
-    A-MPDU of n_mpdu_list (or [mpdu]), HT-SIG aggregation bit set."""
+    A-MPDU of n_mpdu_list (or [mpdu]), HT-SIG aggregation bit set.  short_gi (HT / VHT): the SIG field's
+    short-GI bit is set and the data symbols carry an 8-sample guard interval (72 samples each); the L-SIG
+    length stays the long-GI one, which covers the shorter frame."""
     m = Mod(fmt, mcs, nss)
     nss = m.nss
     if fmt == F_VHT:
@@ -289,7 +291,7 @@ def gen_frame(fmt, mcs, nss, mpdu, scrambler=93, n_mpdu_list=None, ht_aggregate=
     sigb_crc = [0] * 8
     if fmt == F_HT:
         b = [(mcs >> i) & 1 for i in range(7)] + [0] + [(m.psdu >> i) & 1 for i in range(16)]
-        b += [1, 1, 1, 1 if ht_aggregate else 0, 0, 0, 0, 0, 0, 0]   # smoothing, not sounding, reserved, aggregation, stbc x2, bcc, long GI, ess x2
+        b += [1, 1, 1, 1 if ht_aggregate else 0, 0, 0, 0, 1 if short_gi else 0, 0, 0]   # smoothing, not sounding, reserved, aggregation, stbc x2, bcc, long GI, ess x2
         b = b + crc8_bits(b) + [0] * 6
         c = bcc_encode(b)
         for iss in range(nss):
@@ -297,7 +299,7 @@ def gen_frame(fmt, mcs, nss, mpdu, scrambler=93, n_mpdu_list=None, ht_aggregate=
             segs[iss].append(_sig_symbol(c[48:], True, nss, iss))
     elif fmt == F_VHT:
         b = [0, 0, 1, 0] + [0] * 6 + [((nss - 1) >> i) & 1 for i in range(3)] + [0] * 9 + [0, 1]
-        b += [0, 0, 0, 0] + [(mcs >> i) & 1 for i in range(4)] + [0, 1]
+        b += [1 if short_gi else 0, 0, 0, 0] + [(mcs >> i) & 1 for i in range(4)] + [0, 1]
         b = b + crc8_bits(b) + [0] * 6
         c = bcc_encode(b)
         for iss in range(nss):
@@ -343,6 +345,11 @@ def gen_frame(fmt, mcs, nss, mpdu, scrambler=93, n_mpdu_list=None, ht_aggregate=
         scr[16 + 8 * m.psdu: 16 + 8 * m.psdu + 6] = 0
     assert len(scr) == m.nsym * m.ndbps
     coded = puncture(bcc_encode(scr), m.cr)
+    if fmt == F_VHT and mcs == 9 and m.ndbps * 6 != m.ncbps * 5:
+        # VHT MCS9 at 20 MHz with one or two streams is not a combination of the standard (N_DBPS is not an
+        # integer); the reference receiver takes it with N_DBPS rounded down (lib/cloud80211phy.cc:1287-1303)
+        # and reads the coded bits as one continuous stream, so the symbols' spare bits all come at the end
+        coded = np.concatenate([coded, np.zeros(m.nsym * m.ncbps - len(coded), dtype=np.uint8)])
     assert len(coded) == m.nsym * m.ncbps
     # ---- stream parse, interleave, map, OFDM
     s = max(m.nbpscs // 2, 1)
@@ -370,7 +377,8 @@ def gen_frame(fmt, mcs, nss, mpdu, scrambler=93, n_mpdu_list=None, ht_aggregate=
             pil = [pil0[(k + n) % 4] if rot else pil0[k] for k in range(4)]
             pil = [p * PILOT_PS[(pidx + n) % 127] for p in pil]
             tones = _insert_pilots_dc(pts[n], pil, m.nsd)
-            segs[iss].append(_gi(_to_time(tones, -26 if fmt == F_L else -28, ntf, nss, cs)))
+            body = _to_time(tones, -26 if fmt == F_L else -28, ntf, nss, cs)
+            segs[iss].append(np.concatenate([body[56:], body]) if short_gi and fmt != F_L else _gi(body))
     # ---- join: halve the two samples either side of every boundary
     out = []
     for iss in range(nss):

@@ -180,6 +180,47 @@ def test_garbage_and_truncated_frames_dropped(pkg, rxctx, oracle):
     assert r[0]["n_pdu"] == 0 and r[1]["n_pdu"] == 0 and r[2]["status"] == 1
 
 
+def test_short_guard_interval_is_a_stride_only(pkg, rxctx, oracle):
+    """Short-GI frames: the reference steps 72 samples per data symbol but keeps its 8-sample window offset and
+    the long-GI channel estimate (lib/cloud80211phy.cc:898-902, 1155-1159), so it does not recover the payload.
+    The GPU follows it sample for sample: same tags, same soft bits, same (failed) FCS verdicts."""
+    tx = pkg.txgen
+    rng = np.random.default_rng(31)
+    frames = []
+    for fmt, mcs, nss in ((1, 3, 1), (2, 5, 1), (1, 11, 2), (2, 2, 2)):
+        sig, m = tx.gen_frame(fmt, mcs, nss, tx.make_mpdu(220, rng), short_gi=True)
+        sig = sig * 12.0 * np.sqrt(m.nss)
+        rx = awgn(H22 @ sig if m.nss == 2 else sig, 35.0, rng)
+        pad = np.zeros((rx.shape[0], 30))
+        rx = np.concatenate([pad, rx, pad], axis=1).astype(np.complex64)
+        frames.append(([rx[a] for a in range(rx.shape[0])], 206))
+    r = run_rx(pkg, rxctx, oracle, [f for f in frames if len(f[0]) == 1])
+    r += run_rx(pkg, rxctx, oracle, [f for f in frames if len(f[0]) == 2])
+    assert all(ref["status"] == 0 and ref["frame"].m.nSymSamp == 72 for ref in r)
+
+
+def test_vht_mcs9_with_truncated_ndbps(pkg, rxctx, oracle):
+    """VHT MCS9 at 20 MHz: not a combination of the standard for one or two streams, but the reference receiver
+    takes it with N_DBPS = 346 (693 for two streams) from an integer division (lib/cloud80211phy.cc:1287-1303)
+    and decodes the coded bits as one continuous stream.  Same here: the payload comes back."""
+    tx = pkg.txgen
+    rng = np.random.default_rng(32)
+    for nss in (1, 2):
+        frames, mpdus = [], []
+        for nb in (60, 300, 1500, 2999):
+            mp = tx.make_mpdu(nb, rng)
+            sig, m = tx.gen_frame(tx.F_VHT, 9, nss, mp)
+            sig = sig * 12.0 * np.sqrt(m.nss)
+            rx = awgn(H22 @ sig if m.nss == 2 else sig, 38.0, rng)
+            pad = np.zeros((rx.shape[0], 30))
+            rx = np.concatenate([pad, rx, pad], axis=1).astype(np.complex64)
+            frames.append(([rx[a] for a in range(rx.shape[0])], 206))
+            mpdus.append(mp)
+        r = run_rx(pkg, rxctx, oracle, frames)
+        for ref, mp in zip(r, mpdus):
+            assert ref["frame"].m.nDBPS == 346 * nss + (nss - 1) and [p["mpdu"] for p in ref["pdus"]] == [mp]
+
+
 def test_vht_multi_subframe_ampdu(pkg, rxctx, oracle):
     tx = pkg.txgen
     rng = np.random.default_rng(26)

@@ -53,6 +53,40 @@ def test_vht_multi_mpdu_ampdu(pkg, oracle):
     assert [p["mpdu"] for p in r["pdus"]] == ms
 
 
+@pytest.mark.parametrize("nss", [1, 2])
+def test_vht_mcs9_roundtrip_with_truncated_ndbps(pkg, oracle, nss):
+    """VHT MCS9 at 20 MHz: the receiver's N_DBPS comes out of an integer division (346 per stream and a third
+    lost, lib/cloud80211phy.cc:1287-1303); a transmitter that pads at the end of the coded stream is decoded."""
+    tx = pkg.txgen
+    rng = np.random.default_rng(900 + nss)
+    mpdu = tx.make_mpdu(700, rng)
+    sig, m = tx.gen_frame(tx.F_VHT, 9, nss, mpdu)
+    sig = sig * 12.0 * np.sqrt(m.nss)
+    rx = awgn(H22 @ sig if m.nss == 2 else sig, 38.0, rng)
+    pad = np.zeros((rx.shape[0], 50))
+    rx = np.concatenate([pad, rx, pad], axis=1).astype(np.complex64)
+    r = oracle.rx_frame(rx[0], rx[1] if m.nss == 2 else None, 50 + 176, 0.0)
+    assert r["status"] == 0 and r["frame"].m.nDBPS == (346, 693)[nss - 1]
+    assert [p["mpdu"] for p in r["pdus"]] == [mpdu]
+
+
+@pytest.mark.parametrize("fmt,mcs,nss", [(1, 3, 1), (2, 5, 1), (1, 11, 2)])
+def test_short_gi_changes_the_stride_only(pkg, oracle, fmt, mcs, nss):
+    """The short-GI bit of HT-SIG / VHT-SIG-A makes the receiver step 72 samples per data symbol
+    (lib/cloud80211phy.cc:898-902, 1155-1159) and nothing else, so the payload of a real short-GI frame is lost."""
+    tx = pkg.txgen
+    rng = np.random.default_rng(950 + mcs)
+    sig, m = tx.gen_frame(fmt, mcs, nss, tx.make_mpdu(150, rng), short_gi=True)
+    assert sig.shape[1] == m.n_samples() - 8 * m.nsym
+    sig = sig * 12.0 * np.sqrt(m.nss)
+    rx = H22 @ sig if m.nss == 2 else sig
+    pad = np.zeros((rx.shape[0], 50))
+    rx = np.concatenate([pad, rx, pad], axis=1).astype(np.complex64)
+    r = oracle.rx_frame(rx[0], rx[1] if m.nss == 2 else None, 50 + 176, 0.0)
+    assert r["status"] == 0 and r["frame"].m.nSymSamp == 72 and r["frame"].m.nSym == m.nsym
+    assert r["n_pdu"] == 0
+
+
 def test_reference_bit_vectors(pkg):
     """The stages of the transmitter against the bit vectors in the reference's tools/txbits.py: scrambler (seed
     93) with the tail zeroed afterwards, convolutional encoder, HT BPSK interleaver, and the coded and interleaved
