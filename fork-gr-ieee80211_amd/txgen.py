@@ -257,12 +257,15 @@ def ampdu_vht(mpdus, eof=None):
     return out
 
 
-def gen_frame(fmt, mcs, nss, mpdu, scrambler=93, n_mpdu_list=None, ht_aggregate=False, short_gi=False):
+def gen_frame(fmt, mcs, nss, mpdu, scrambler=93, n_mpdu_list=None, ht_aggregate=False, short_gi=False, sig_edit=None):
     """Baseband frame(s): returns (array [nss][N] complex128, Mod).  For VHT `mpdu` is wrapped into a
     single-subframe A-MPDU (pass n_mpdu_list=[m0, m1, ...] for several subframes).  ht_aggregate: HT PSDU =
     A-MPDU of n_mpdu_list (or [mpdu]), HT-SIG aggregation bit set.  short_gi (HT / VHT): the SIG field's
     short-GI bit is set and the data symbols carry an 8-sample guard interval (72 samples each); the L-SIG
-    length stays the long-GI one, which covers the shorter frame."""
+    length stays the long-GI one, which covers the shorter frame.  sig_edit(name, bits) -> bits, for malformed
+    frames: called with the bit list of every SIG field before its parity / CRC is computed ("lsig", "htsig",
+    "vhta", "vhtb") and again with the protected field (name + "_crc"); whatever it returns is sent."""
+    edit = sig_edit if sig_edit is not None else (lambda name, bits: bits)
     m = Mod(fmt, mcs, nss)
     nss = m.nss
     if fmt == F_VHT:
@@ -283,8 +286,8 @@ def gen_frame(fmt, mcs, nss, mpdu, scrambler=93, n_mpdu_list=None, ht_aggregate=
         segs[iss].append(np.concatenate([ltf[32:], ltf, ltf]))
     # ---- L-SIG
     rate = L_RATE_BITS[mcs] if fmt == F_L else L_RATE_BITS[0]
-    hb = list(rate) + [0] + [(m.lsig_len >> i) & 1 for i in range(12)]
-    hb = hb + [sum(hb) % 2] + [0] * 6
+    hb = edit("lsig", list(rate) + [0] + [(m.lsig_len >> i) & 1 for i in range(12)])
+    hb = edit("lsig_crc", hb + [sum(hb) % 2] + [0] * 6)
     lsig = bcc_encode(hb)
     for iss in range(nss):
         segs[iss].append(_sig_symbol(lsig, False, nss, iss))
@@ -292,7 +295,8 @@ def gen_frame(fmt, mcs, nss, mpdu, scrambler=93, n_mpdu_list=None, ht_aggregate=
     if fmt == F_HT:
         b = [(mcs >> i) & 1 for i in range(7)] + [0] + [(m.psdu >> i) & 1 for i in range(16)]
         b += [1, 1, 1, 1 if ht_aggregate else 0, 0, 0, 0, 1 if short_gi else 0, 0, 0]   # smoothing, not sounding, reserved, aggregation, stbc x2, bcc, long GI, ess x2
-        b = b + crc8_bits(b) + [0] * 6
+        b = edit("htsig", b)
+        b = edit("htsig_crc", b + crc8_bits(b) + [0] * 6)
         c = bcc_encode(b)
         for iss in range(nss):
             segs[iss].append(_sig_symbol(c[:48], True, nss, iss))
@@ -300,7 +304,8 @@ def gen_frame(fmt, mcs, nss, mpdu, scrambler=93, n_mpdu_list=None, ht_aggregate=
     elif fmt == F_VHT:
         b = [0, 0, 1, 0] + [0] * 6 + [((nss - 1) >> i) & 1 for i in range(3)] + [0] * 9 + [0, 1]
         b += [1 if short_gi else 0, 0, 0, 0] + [(mcs >> i) & 1 for i in range(4)] + [0, 1]
-        b = b + crc8_bits(b) + [0] * 6
+        b = edit("vhta", b)
+        b = edit("vhta_crc", b + crc8_bits(b) + [0] * 6)
         c = bcc_encode(b)
         for iss in range(nss):
             segs[iss].append(_sig_symbol(c[:48], False, nss, iss))
@@ -320,7 +325,7 @@ def gen_frame(fmt, mcs, nss, mpdu, scrambler=93, n_mpdu_list=None, ht_aggregate=
     # ---- VHT-SIG-B
     if fmt == F_VHT:
         ln = -(-m.apep // 4)
-        b = [(ln >> i) & 1 for i in range(17)] + [1, 1, 1]
+        b = edit("vhtb", [(ln >> i) & 1 for i in range(17)] + [1, 1, 1])
         sigb_crc = crc8_bits(b)
         c = bcc_encode(b + [0] * 6)
         il = np.zeros(52, dtype=np.uint8)

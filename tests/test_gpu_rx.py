@@ -3,7 +3,7 @@ golden fixtures: PSDU bytes and FCS verdicts bit-exact, tags equal, soft bits wi
 import numpy as np
 import pytest
 
-from util import H22, LLR_ATOL, LLR_RTOL, awgn, build_arena, golden_frames, ref_fixture_mpdu, ref_fixtures
+from util import H22, LLR_ATOL, LLR_RTOL, MALFORMED, awgn, build_arena, golden_frames, ref_fixture_mpdu, ref_fixtures
 
 pytestmark = pytest.mark.gpu
 
@@ -219,6 +219,24 @@ def test_vht_mcs9_with_truncated_ndbps(pkg, rxctx, oracle):
         r = run_rx(pkg, rxctx, oracle, frames)
         for ref, mp in zip(r, mpdus):
             assert ref["frame"].m.nDBPS == 346 * nss + (nss - 1) and [p["mpdu"] for p in ref["pdus"]] == [mp]
+
+
+def test_malformed_sig_fields(pkg, rxctx, oracle):
+    """Frames whose SIG fields the reference rejects, misreads or accepts although the standard would not: the
+    same verdict, tags, soft bits and output for each (run_rx compares them all)."""
+    tx = pkg.txgen
+    rng = np.random.default_rng(33)
+    frames = []
+    for fmt, mcs, edit in MALFORMED:
+        sig, m = tx.gen_frame(fmt, mcs, 1, tx.make_mpdu(94, rng), sig_edit=edit)
+        rx = np.concatenate([np.zeros(30), awgn(sig * 12.0, 35.0, rng)[0], np.zeros(400)]).astype(np.complex64)
+        frames.append(([rx], 206))
+    r = run_rx(pkg, rxctx, oracle, frames, check_llr=False)
+    statuses = [ref["status"] for ref in r]
+    assert sum(1 for s in statuses if s != 0) >= 8, statuses
+    assert sum(ref["n_pdu"] for ref in r) >= 3, statuses     # the fields nobody looks at do no harm
+    # the same frames on the two-antenna path
+    run_rx(pkg, rxctx, oracle, [([f[0][0], 0.5 * f[0][0]], f[1]) for f in frames], check_llr=False)
 
 
 def test_vht_multi_subframe_ampdu(pkg, rxctx, oracle):

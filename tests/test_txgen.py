@@ -2,7 +2,7 @@
 import numpy as np
 import pytest
 
-from util import H22, awgn, golden_frames
+from util import H22, MALFORMED, awgn, golden_frames
 
 
 @pytest.mark.parametrize("fr", [f for f in golden_frames() if f["rad"] == 0.0], ids=lambda f: f["name"])
@@ -85,6 +85,24 @@ def test_short_gi_changes_the_stride_only(pkg, oracle, fmt, mcs, nss):
     r = oracle.rx_frame(rx[0], rx[1] if m.nss == 2 else None, 50 + 176, 0.0)
     assert r["status"] == 0 and r["frame"].m.nSymSamp == 72 and r["frame"].m.nSym == m.nsym
     assert r["n_pdu"] == 0
+
+
+def test_malformed_sig_fields_through_oracle(pkg, oracle):
+    """What the receiver makes of SIG fields that break a rule: dropped at L-SIG (status 1), decoded as a legacy
+    frame of the L-SIG length when HT-SIG / VHT-SIG-A fail their checks (format 0, no packet), dropped on an
+    unsupported stream count or a bad VHT-SIG-B, and decoded normally when only an unchecked bit differs."""
+    tx = pkg.txgen
+    rng = np.random.default_rng(33)
+    seen = []
+    for fmt, mcs, edit in MALFORMED:
+        sig, m = tx.gen_frame(fmt, mcs, 1, tx.make_mpdu(94, rng), sig_edit=edit)
+        rx = np.concatenate([np.zeros(30), sig[0] * 12.0, np.zeros(400)]).astype(np.complex64)
+        r = oracle.rx_frame(rx, None, 206, 0.0)
+        seen.append((r["status"], r["frame"].m.format if r["status"] == 0 else -1, r["n_pdu"]))
+    assert seen[:4] == [(1, -1, 0)] * 4
+    assert seen[4:11] == [(0, 0, 0)] * 7 and seen[11] == (0, 1, 1)
+    assert seen[12:17] == [(0, 0, 0)] * 5 and seen[17:19] == [(0, 2, 1)] * 2
+    assert all(s[0] != 0 and s[2] == 0 for s in seen[19:])
 
 
 def test_reference_bit_vectors(pkg):

@@ -114,3 +114,40 @@ def model_chain(oracle, iq0, iq1, triggers):
     return out, n_frames
 
 
+def flip(name, *idx):
+    def edit(which, bits):
+        if which == name:
+            bits = list(bits)
+            for i in idx:
+                bits[i] ^= 1
+        return bits
+    return edit
+
+
+# (format, mcs, SIG edit): what signalCheckLegacy / signalCheckHt / signalCheckVhtA and the parsers reject or
+# let through (lib/cloud80211phy.cc:650-771, 852-1223)
+MALFORMED = [
+    (0, 3, flip("lsig", 4)),            # L-SIG reserved bit
+    (0, 3, flip("lsig_crc", 17)),       # L-SIG parity
+    (0, 3, flip("lsig", 3)),            # rate field without its top bit
+    (0, 0, flip("lsig", 5, 6, 9, 11)),  # length 94 -> 13, below the shortest frame (four flips: parity unchanged)
+    (1, 4, flip("htsig", 26)),          # HT-SIG reserved one
+    (1, 4, flip("htsig_crc", 36)),      # HT-SIG CRC
+    (1, 4, flip("htsig", 7)),           # 40 MHz
+    (1, 4, flip("htsig", 28)),          # STBC
+    (1, 4, flip("htsig", 30)),          # LDPC
+    (1, 4, flip("htsig", 32)),          # extension spatial streams
+    (1, 4, flip("htsig", 5)),           # MCS 36
+    (1, 4, flip("htsig", 24)),          # smoothing: not looked at
+    (2, 4, flip("vhta", 2)),            # VHT-SIG-A reserved ones
+    (2, 4, flip("vhta", 23)),
+    (2, 4, flip("vhta", 33)),
+    (2, 4, flip("vhta", 0)),            # 40 MHz
+    (2, 4, flip("vhta_crc", 40)),       # VHT-SIG-A CRC
+    (2, 4, flip("vhta", 3)),            # STBC: not looked at
+    (2, 4, flip("vhta", 26)),           # LDPC: not looked at
+    (2, 4, flip("vhta", 29, 31)),       # MCS 4 -> 14
+    (2, 4, flip("vhta", 11)),           # three space-time streams
+    (2, 4, flip("vhta", 5)),            # group id 2: a multi-user frame
+    (2, 4, flip("vhtb", 18)),           # VHT-SIG-B reserved ones broken, not the NDP pattern either
+]
