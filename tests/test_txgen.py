@@ -102,7 +102,7 @@ def test_malformed_sig_fields_through_oracle(pkg, oracle):
     assert seen[:4] == [(1, -1, 0)] * 4
     assert seen[4:11] == [(0, 0, 0)] * 7 and seen[11] == (0, 1, 1)
     assert seen[12:17] == [(0, 0, 0)] * 5 and seen[17:19] == [(0, 2, 1)] * 2
-    assert all(s[0] != 0 and s[2] == 0 for s in seen[19:])
+    assert all(s[0] != 0 and s[2] == 0 for s in seen[19:26]) and seen[26] == (0, 1, 0)
 
 
 def test_reference_bit_vectors(pkg):

@@ -150,4 +150,8 @@ MALFORMED = [
     (2, 4, flip("vhta", 11)),           # three space-time streams
     (2, 4, flip("vhta", 5)),            # group id 2: a multi-user frame
     (2, 4, flip("vhtb", 18)),           # VHT-SIG-B reserved ones broken, not the NDP pattern either
+    (1, 4, flip("htsig", 23)),          # HT length 94 + 32768: beyond 4095
+    (1, 4, flip("htsig", 16)),          # HT length 94 + 256: more symbols than the L-SIG duration covers
+    (2, 4, flip("vhtb", 8)),            # VHT-SIG-B length + 1024 bytes: the same
+    (1, 4, flip("htsig", 9)),           # HT length 92: decoded two bytes short, the FCS fails
 ]
