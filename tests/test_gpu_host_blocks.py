@@ -13,7 +13,8 @@ from util import H22, blob_of, golden_frames, model_chain, ref_fixtures
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-PUMP = os.path.join(ROOT, "fork-gr-ieee80211_amd", "gr80211_pump")
+# GR80211_PUMP: another build of the same program (e.g. one compiled with host sanitizers)
+PUMP = os.environ.get("GR80211_PUMP") or os.path.join(ROOT, "fork-gr-ieee80211_amd", "gr80211_pump")
 
 
 def run_pump(args):
