@@ -153,8 +153,12 @@ int gr80211_block_work_out(gr80211_block *b, int noutput_items, const int *ninpu
         for (tag_t &x : t) b->out_tags.push_back(std::move(x));  // only port 0 carries tags in these blocks
     }
     int nt = 0;
+    bool tags_lost = false;
     for (const tag_t &x : b->out_tags) {
-        if (!tags_out || nt >= cap_tags_out) break;
+        if (!tags_out || nt >= cap_tags_out) {
+            tags_lost = true;
+            break;
+        }
         int key = -1;
         for (int k = 0; k < kNumTags; k++)
             if (x.key == kTagNames[k]) key = k;
@@ -173,6 +177,10 @@ int gr80211_block_work_out(gr80211_block *b, int noutput_items, const int *ninpu
     if (!b->b->last_error().empty()) {
         b->err = b->b->last_error();
         return -2;
+    }
+    if (tags_lost) {
+        b->err = "gr80211_block_work_out: " + std::to_string(b->out_tags.size()) + " output tags do not fit tags_out";
+        return -3;
     }
     return produced;
 }

@@ -129,7 +129,7 @@ class StreamBlock:
             return consumed.value
         bufs = [np.zeros(noutput_items, OUT_DTYPES[self.kind]) for _ in range(self.n_out)]
         optrs = (ctypes.c_void_p * self.n_out)(*[b.ctypes.data for b in bufs])
-        cap = 4096
+        cap = 16 * (noutput_items // 48 + 1)   # no frame has more than 16 tags or fewer than 48 items
         trecs = (Tag * cap)()
         nt = ctypes.c_int(0)
         produced = self._check(self.lib.gr80211_block_work_out(

@@ -94,8 +94,10 @@ int gr80211_block_work(gr80211_block *b, int noutput_items, const int *ninput_it
                        int n_inputs, const gr80211_tag *tags, int n_tags, int *consumed);
 /*
  * general_work of a block with stream outputs.  output_items: one buffer per output port with room for
- * noutput_items items; tags_out receives the tags of the items produced (at most cap_tags_out; their cvec pointers
- * stay valid until the block's next call).  Returns the items produced on every output port.  A block may hold
+ * noutput_items items; tags_out receives the tags of the items produced (their cvec pointers stay valid until the
+ * block's next call).  A frame carries at most 16 tags and no fewer than 48 items, so cap_tags_out =
+ * 16 * (noutput_items / 48 + 1) always suffices; tags that do not fit are an error (-3), not dropped silently.
+ * Returns the items produced on every output port.  A block may hold
  * produced items back until there is room: gr80211_block_pending_output tells how many, and a call without
  * input (ninput_items all 0) fetches them.
  */

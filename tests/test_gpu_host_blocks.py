@@ -17,9 +17,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PUMP = os.environ.get("GR80211_PUMP") or os.path.join(ROOT, "fork-gr-ieee80211_amd", "gr80211_pump")
 
 
-def run_pump(args):
-    assert os.path.exists(PUMP), "host blocks not built: run __graft_entry__.build()"
-    p = subprocess.run([PUMP] + [str(a) for a in args], capture_output=True, text=True, timeout=170)
+ABI_CHAIN = os.environ.get("GR80211_ABI_CHAIN") or os.path.join(ROOT, "fork-gr-ieee80211_amd", "gr80211_abi_chain")
+
+
+def run_pump(args, prog=PUMP):
+    assert os.path.exists(prog), "host blocks not built: run __graft_entry__.build()"
+    p = subprocess.run([prog] + [str(a) for a in args], capture_output=True, text=True, timeout=170)
     assert p.returncode == 0, (p.returncode, p.stderr[-2000:])
     pdus = [bytes.fromhex(l.split()[1]) for l in p.stdout.splitlines() if l.startswith("PDU ")]
     stat = [l for l in p.stdout.splitlines() if l.startswith("STAT")]
@@ -58,6 +61,21 @@ def siso_stream(noise_sigma, seed):
     if noise_sigma > 0:
         iq0 = (iq0 + noise_sigma * (rng.standard_normal(len(iq0)) + 1j * rng.standard_normal(len(iq0)))).astype(np.complex64)
     return iq0, triggers, frames
+
+
+def mimo_stream(seed):
+    """The two-stream golden frames through the fixed 2x2 channel, back to back on two antennas."""
+    rng = np.random.default_rng(seed)
+    frames = [f for f in golden_frames() if f["nss"] == 2]
+    parts, triggers, pos = [], [], 0
+    for f in frames:
+        r = (H22 @ f["iq"]).astype(np.complex64)
+        parts.append(r)
+        triggers.append((pos + f["sync_idx"], f["rad"]))
+        pos += r.shape[1]
+    iq = np.concatenate(parts, axis=1)
+    iq = (iq + 0.001 * (rng.standard_normal(iq.shape) + 1j * rng.standard_normal(iq.shape))).astype(np.complex64)
+    return iq[0], iq[1], triggers, frames
 
 
 @pytest.mark.parametrize("chunk,batch", [(4096, 1000), (777, 2), (8192, 1)])
@@ -305,16 +323,8 @@ def test_streaming_abi_signal_demod_decode_chain(pkg, oracle, two, chunk, nout, 
     from importlib import import_module
     stream = import_module("fork-gr-ieee80211_amd.stream")
     if two:
-        rng = np.random.default_rng(9)
-        parts, triggers, pos = [], [], 0
-        for f in [f for f in golden_frames() if f["nss"] == 2]:
-            r = (H22 @ f["iq"]).astype(np.complex64)
-            parts.append(r)
-            triggers.append((pos + f["sync_idx"], f["rad"]))
-            pos += r.shape[1]
-        iq = np.concatenate(parts, axis=1)
-        iq = (iq + 0.001 * (rng.standard_normal(iq.shape) + 1j * rng.standard_normal(iq.shape))).astype(np.complex64)
-        ants = [iq[0], iq[1]]
+        a, b, triggers, frames = mimo_stream(9)
+        ants = [a, b]
     else:
         iq0, triggers, frames = siso_stream(0.002, 6)
         ants = [iq0]
@@ -408,3 +418,19 @@ def test_pump_chain_of_three_blocks(tmp_path, oracle, chunk, batch):
     got, stat = run_pump(["chain", 1, chunk, batch, tf] + files)
     assert got == want
     assert "frames=%d " % n_frames in stat + " ", stat
+
+
+@pytest.mark.parametrize("n_rx,chunk,batch", [(1, 4096, 1000), (1, 777, 2), (2, 1500, 3)])
+def test_streaming_abi_from_plain_c(tmp_path, oracle, n_rx, chunk, batch):
+    """signal -> demod -> decode through gr80211_block_work_out / gr80211_block_work from a C program (tags as
+    records, vector values copied between blocks): same messages as the model of the reference's chain."""
+    if n_rx == 1:
+        iq0, triggers, frames = siso_stream(0.002, 6)
+        iq1 = None
+    else:
+        iq0, iq1, triggers, frames = mimo_stream(7)
+    want, n_frames = model_chain(oracle, iq0, iq1, triggers)
+    tf, files = write_stream(tmp_path, iq0, iq1, sorted(triggers))
+    got, stat = run_pump([n_rx, chunk, batch, tf] + files, prog=ABI_CHAIN)
+    assert got == want
+    assert stat == "STAT pdus=%d" % len(want)
