@@ -461,3 +461,55 @@ def test_signal_and_demod_as_separate_stages(pkg, rxctx, oracle):
     bad["mcs"][1] = 9
     info3, _ = rxctx.demod_tagged(o0, o1, bad, n, chan)
     assert int(info3["status"][0]) == 1 and int(info3["status"][1]) == 1 and int(info3["status"][2]) == int(info2["status"][2])
+
+
+def test_two_contexts_on_two_threads(pkg, oracle):
+    """Distinct contexts share nothing: two threads, each with a context and a stream of its own, decode different
+    batches at the same time and get what they get alone (GNU Radio runs every block on a thread of its own)."""
+    import threading
+    import torch
+    tx = pkg.txgen
+    rng = np.random.default_rng(41)
+    jobs = []
+    for k in range(2):
+        frames = [make_noisy(tx, rng, fmt, mcs, 1, int(rng.integers(100, 900)), 33.0)[0]
+                  for fmt, mcs in ((0, 5), (1, 7), (2, 8), (2, 3)) * (6 + 4 * k)]
+        iq0, _, sync, navail = build_arena(frames)
+        jobs.append((iq0, sync, navail, len(frames)))
+
+    def run(job, reps):
+        iq0, sync, navail, n = job
+        ctx = pkg.RxContext(0)
+        outs = []
+        with torch.cuda.stream(torch.cuda.Stream()):
+            d0 = torch.from_numpy(iq0).cuda()
+            desc = ctx.make_desc(sync, navail)
+            for _ in range(reps):
+                res = ctx.rx_batch(d0, None, desc, n)
+                ctx.sync()
+                ln = res["out_len"].cpu().numpy()
+                out = res["out"].cpu().numpy()
+                outs.append((res["n_pdu"].cpu().numpy().copy(), [bytes(out[i, : ln[i]]) for i in range(n)]))
+        ctx.close()
+        return outs
+
+    alone = [run(job, 1)[0] for job in jobs]
+    assert all(int(a[0].sum()) == job[3] for a, job in zip(alone, jobs))
+    got, errors = [None, None], []
+
+    def worker(k):
+        try:
+            got[k] = run(jobs[k], 12)
+        except Exception as e:  # noqa: BLE001 - reported below, from the main thread
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(150)
+    assert not errors and not any(t.is_alive() for t in threads), errors
+    for k in range(2):
+        for rep in got[k]:
+            assert np.array_equal(rep[0], alone[k][0]) and rep[1] == alone[k][1]
+
