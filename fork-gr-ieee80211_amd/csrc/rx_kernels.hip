@@ -1120,6 +1120,9 @@ __global__ __launch_bounds__(64 * DEMOD_WAVES) void k_demod(const c32 *__restric
     const int st = info[f].status;
     if (!(st == GR80211_ST_OK || st == GR80211_ST_DROP_DECODE_LIMIT)) return;
     if ((info[f].nSS == 1) != (NSS == 1)) return;
+    // Beside the decoder waves of another batch in flight this kernel's short, memory-bound waves go first: the
+    // decoder's waves alternate between priorities 2 and 0 and would otherwise keep them from issuing most of the time.
+    __builtin_amdgcn_s_setprio(3);
     __shared__ __attribute__((aligned(16))) float s_stage[DEMOD_WAVES][DEMOD_STAGE / 2 * NSS];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // symbol counters stay scalar
