@@ -89,34 +89,56 @@ __device__ __forceinline__ c32 load_samp(const c32 *in, int k, int nvalid, float
 }
 
 // Rate-1/2 64-state soft Viterbi over <= 48 steps with one trellis state per lane
-// (svSigDecoder::decode, lib/cloud80211phy.cc:2001-2088).  llr, masks and bits live in LDS.
-__device__ void wave_sig_viterbi(const float *llr, int T, unsigned long long *masks, uint8_t *bits, int lane)
+// (svSigDecoder::decode, lib/cloud80211phy.cc:2001-2088).  llr and bits live in LDS.  The decision mask of step t
+// (one bit per state, a wave-wide ballot) is parked in lane t of a register pair, and the walk back from state 0 runs
+// on the scalar unit: no memory, no single-lane vector code.
+__device__ __forceinline__ float pick3(float t1, float t0, float t01, uint32_t k1, uint32_t k2, uint32_t k3)
+{
+    // one of the three values, or 0.0f: the masks are all ones for at most one of them (no branches, no selects
+    // the compiler could turn into branches)
+    return __uint_as_float((__float_as_uint(t1) & k1) | (__float_as_uint(t0) & k2) | (__float_as_uint(t01) & k3));
+}
+
+// One add-compare-select step of the state in this lane; the decision goes into bit `bit` of hist.
+__device__ __forceinline__ void sig_acs(float &m, uint32_t &hist, float t0, float t1, int p0, int p1, uint32_t bit,
+                                        uint32_t a1, uint32_t a2, uint32_t a3, uint32_t b1, uint32_t b2, uint32_t b3)
+{
+    const float t01 = t1 + t0;
+    const float m0 = __shfl(m, p0), m1 = __shfl(m, p1);
+    const float c0 = m0 + pick3(t1, t0, t01, a1, a2, a3), c1 = m1 + pick3(t1, t0, t01, b1, b2, b3);
+    const bool g = c1 > c0;  // ties keep the even predecessor, as the reference's strict '>' does
+    m = g ? c1 : c0;
+    hist |= g ? bit : 0u;
+}
+
+__device__ __forceinline__ void wave_sig_viterbi(const float *llr, int T, uint8_t *bits, int lane)
 {
     const int j = lane & 31, b = lane >> 5, p0 = 2 * j, p1 = 2 * j + 1;
     const int o0 = sv_out(p0, b), o1 = sv_out(p1, b);
+    // branch metric of output pair o: 0, t1, t0, t1 + t0 for o = 0..3
+    const uint32_t a1 = o0 == 1 ? ~0u : 0u, a2 = o0 == 2 ? ~0u : 0u, a3 = o0 == 3 ? ~0u : 0u;
+    const uint32_t b1 = o1 == 1 ? ~0u : 0u, b2 = o1 == 2 ? ~0u : 0u, b3 = o1 == 3 ? ~0u : 0u;
     float m = lane == 0 ? 0.0f : NEG_INIT;
+    // every lane keeps the decisions of its own state, one bit per step; the walk back from state 0 then runs on
+    // the scalar unit, fetching the word of the state it stands on with a lane read: no memory, no one-lane code
+    uint32_t hlo = 0, hhi = 0;
+    const int Tlo = T < 32 ? T : 32;
     __syncthreads();
-    for (int t = 0; t < T; t++) {
-        const float t0 = llr[2 * t], t1 = llr[2 * t + 1];
-        const float t01 = t1 + t0;
-        const float m0 = __shfl(m, p0), m1 = __shfl(m, p1);
-        const float bm0 = o0 == 0 ? 0.0f : o0 == 1 ? t1 : o0 == 2 ? t0 : t01;
-        const float bm1 = o1 == 0 ? 0.0f : o1 == 1 ? t1 : o1 == 2 ? t0 : t01;
-        const float a0 = m0 + bm0, a1 = m1 + bm1;
-        const bool g = a1 > a0;  // ties keep the even predecessor, as the reference's strict '>' does
-        m = g ? a1 : a0;
-        const unsigned long long mk64 = __ballot(g);
-        if (lane == 0) masks[t] = mk64;
+    for (int t = 0; t < Tlo; t++) sig_acs(m, hlo, llr[2 * t], llr[2 * t + 1], p0, p1, 1u << t, a1, a2, a3, b1, b2, b3);
+    for (int t = 32; t < T; t++) sig_acs(m, hhi, llr[2 * t], llr[2 * t + 1], p0, p1, 1u << (t - 32), a1, a2, a3, b1, b2, b3);
+    unsigned long long decoded = 0;
+    int st = 0;
+    for (int t = T - 1; t >= 32; t--) {
+        decoded |= (unsigned long long)(st >> 5) << t;
+        const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)hhi, st);
+        st = ((st & 31) << 1) | (int)((w >> (t - 32)) & 1u);
     }
-    __syncthreads();
-    if (lane == 0) {
-        int s = 0;
-        for (int t = T - 1; t >= 0; t--) {
-            bits[t] = (uint8_t)(s >> 5);
-            const int d = (int)((masks[t] >> s) & 1ull);
-            s = ((s & 31) << 1) | d;
-        }
+    for (int t = Tlo - 1; t >= 0; t--) {
+        decoded |= (unsigned long long)(st >> 5) << t;
+        const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)hlo, st);
+        st = ((st & 31) << 1) | (int)((w >> t) & 1u);
     }
+    if (lane < T) bits[lane] = (uint8_t)((decoded >> lane) & 1ull);
     __syncthreads();
 }
 
@@ -357,7 +379,6 @@ __global__ __launch_bounds__(64) void k_preamble(const c32 *__restrict__ iq0, co
     const int bin = brev6(lane);
 
     __shared__ float s_llr[2][96];
-    __shared__ unsigned long long s_mask[48];
     __shared__ uint8_t s_bits[48];
     __shared__ ModS s_m;
     __shared__ int s_ctl[8];  // 0 status, 1 lsig_mcs, 2 lsig_len, 3 nsamp, 4 fmt, 5 trellis, 6 data_off, 7 MU frame
@@ -436,7 +457,7 @@ __global__ __launch_bounds__(64) void k_preamble(const c32 *__restrict__ iq0, co
         const c32 ps = cconj(cadd(cadd(csub(e7, e21), e43), e57));
         const float pa = cabs32(ps);
         if (demap >= 0) s_llr[0][demap] = cdivf(cmul(e, ps), pa).x;
-        wave_sig_viterbi(s_llr[0], 24, s_mask, s_bits, lane);
+        wave_sig_viterbi(s_llr[0], 24, s_bits, lane);
         if (lane == 0) {
             int mcs = 0, len = 0, ndbps = 24;
             if (!check_legacy(s_bits, &mcs, &len, &ndbps)) {
@@ -473,7 +494,7 @@ __global__ __launch_bounds__(64) void k_preamble(const c32 *__restrict__ iq0, co
             s_llr[1][demap] = m1.y;       // HT-SIG: QBPSK twice
             s_llr[1][demap + 48] = m2.y;
         }
-        wave_sig_viterbi(s_llr[0], 48, s_mask, s_bits, lane);
+        wave_sig_viterbi(s_llr[0], 48, s_bits, lane);
         if (lane == 0) {
             if (check_vhta(s_bits)) {
                 s_ctl[4] = GR80211_F_VHT;
@@ -488,7 +509,7 @@ __global__ __launch_bounds__(64) void k_preamble(const c32 *__restrict__ iq0, co
         __syncthreads();
         if (s_ctl[0] != GR80211_ST_OK) goto finish;
         if (s_ctl[4] == -1) {
-            wave_sig_viterbi(s_llr[1], 48, s_mask, s_bits, lane);
+            wave_sig_viterbi(s_llr[1], 48, s_bits, lane);
             if (lane == 0) {
                 if (check_ht(s_bits)) {
                     s_ctl[4] = GR80211_F_HT;
@@ -634,7 +655,7 @@ __global__ __launch_bounds__(64) void k_preamble(const c32 *__restrict__ iq0, co
                 inted = (q0.x + q1.x) / 2.0f;
             }
             if (jn >= 0) s_llr[0][c_tab.deint_nl[0][jn]] = inted;
-            wave_sig_viterbi(s_llr[0], 26, s_mask, s_bits, lane);
+            wave_sig_viterbi(s_llr[0], 26, s_bits, lane);
             // per-stream SNR from the re-encoded SIG-B (float64 accumulation as in the reference)
             double n0 = 0.0, n1 = 0.0;
             if (jn >= 0) {
