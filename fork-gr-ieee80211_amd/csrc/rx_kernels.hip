@@ -89,7 +89,7 @@ __device__ __forceinline__ c32 load_samp(const c32 *in, int k, int nvalid, float
 }
 
 // Rate-1/2 64-state soft Viterbi over <= 48 steps with one trellis state per lane
-// (svSigDecoder::decode, lib/cloud80211phy.cc:2001-2088).  llr and bits live in LDS.  The decision mask of step t
+// (svSigDecoder::decode, lib/cloud80211phy.cc:2001-2088).  llr lives in LDS; the decoded bits come back as one word.  The decision mask of step t
 // (one bit per state, a wave-wide ballot) is parked in lane t of a register pair, and the walk back from state 0 runs
 // on the scalar unit: no memory, no single-lane vector code.
 __device__ __forceinline__ float pick3(float t1, float t0, float t01, uint32_t k1, uint32_t k2, uint32_t k3)
@@ -111,7 +111,7 @@ __device__ __forceinline__ void sig_acs(float &m, uint32_t &hist, float t0, floa
     hist |= g ? bit : 0u;
 }
 
-__device__ __forceinline__ void wave_sig_viterbi(const float *llr, int T, uint8_t *bits, int lane)
+__device__ __forceinline__ unsigned long long wave_sig_viterbi(const float *llr, int T, int lane)
 {
     const int j = lane & 31, b = lane >> 5, p0 = 2 * j, p1 = 2 * j + 1;
     const int o0 = sv_out(p0, b), o1 = sv_out(p1, b);
@@ -138,8 +138,7 @@ __device__ __forceinline__ void wave_sig_viterbi(const float *llr, int T, uint8_
         const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)hlo, st);
         st = ((st & 31) << 1) | (int)((w >> t) & 1u);
     }
-    if (lane < T) bits[lane] = (uint8_t)((decoded >> lane) & 1ull);
-    __syncthreads();
+    return decoded;  // bit t = decoded bit t, the same value in every lane (scalar registers)
 }
 
 // ---- SIG field checks and parsers (run by lane 0 on bits in LDS) -------------------------
@@ -147,7 +146,14 @@ struct ModS {
     int format, ampdu, nSym, nSymSamp, nSD, nSS, nLTF, mcs, len, mod, cr, nBPSCS, nDBPS, nCBPS, nCBPSS;
 };
 
-__device__ unsigned crc8_run(const uint8_t *in, int n)
+// The decoded bits of a SIG field, bit i of the word = bit i of the field.  The word is wave-uniform, so what the
+// checks and parsers below do with it runs on the scalar unit.
+struct SigBits {
+    unsigned long long w;
+    __device__ __forceinline__ unsigned operator[](int i) const { return (unsigned)((w >> i) & 1ull); }
+};
+
+__device__ __forceinline__ unsigned crc8_run(SigBits in, int n)
 {
     unsigned c = 0xff;
     for (int i = 0; i < n; i++) {
@@ -157,22 +163,22 @@ __device__ unsigned crc8_run(const uint8_t *in, int n)
     }
     return c;
 }
-__device__ bool crc8_check(const uint8_t *in, int n, const uint8_t *crc)
+__device__ __forceinline__ bool crc8_check(SigBits in, int n)  // the CRC's eight bits follow the n it covers
 {
     unsigned c = crc8_run(in, n);
     for (int i = 0; i < 8; i++)
-        if (crc[i]) c ^= 1u << (7 - i);
+        if (in[n + i]) c ^= 1u << (7 - i);
     return (c & 0xff) == 0xff;
 }
 
 // lib/cloud80211phy.cc:650-728
-__device__ bool check_legacy(const uint8_t *b, int *mcs, int *len, int *ndbps)
+__device__ __forceinline__ bool check_legacy(SigBits b, int *mcs, int *len, int *ndbps)
 {
     if (!b[3]) return false;
     if (b[4]) return false;
     unsigned sum = 0;
     for (int i = 0; i < 17; i++) sum += b[i];
-    if ((sum & 1) ^ b[17]) return false;
+    if ((sum & 1u) ^ b[17]) return false;
     int rate = 0;
     for (int i = 0; i < 4; i++) rate |= b[i] << i;
     switch (rate) {
@@ -192,18 +198,18 @@ __device__ bool check_legacy(const uint8_t *b, int *mcs, int *len, int *ndbps)
     return !(l > 4095 || l < 14);
 }
 // lib/cloud80211phy.cc:730-751
-__device__ bool check_ht(const uint8_t *b)
+__device__ __forceinline__ bool check_ht(SigBits b)
 {
     if (b[26] != 1) return false;
-    if (!crc8_check(b, 34, &b[34])) return false;
+    if (!crc8_check(b, 34)) return false;
     if (b[5] + b[6] + b[7] + b[28] + b[29] + b[30] + b[32] + b[33]) return false;
     return true;
 }
 // lib/cloud80211phy.cc:753-771
-__device__ bool check_vhta(const uint8_t *b)
+__device__ __forceinline__ bool check_vhta(SigBits b)
 {
     if (b[2] != 1 || b[23] != 1 || b[33] != 1) return false;
-    if (!crc8_check(b, 34, &b[34])) return false;
+    if (!crc8_check(b, 34)) return false;
     if (b[0] + b[1]) return false;
     return true;
 }
@@ -241,7 +247,7 @@ __device__ void set_rate_ladder(int r, ModS *m)
     m->mod = mod[r]; m->nBPSCS = nbp[r]; m->cr = cr[r];
 }
 // lib/cloud80211phy.cc:852-998
-__device__ void parse_ht(const uint8_t *b, ModS *m)
+__device__ __forceinline__ void parse_ht(SigBits b, ModS *m)
 {
     int mcs = 0, len = 0;
     for (int i = 0; i < 7; i++) mcs |= b[i] << i;
@@ -276,7 +282,7 @@ __device__ bool set_vht_mcs(int mcs, ModS *m)
 }
 // lib/cloud80211phy.cc:1090-1178.  Returns 1 for a single-user frame, 2 for an MU frame (group id 1..62: one
 // stream for this station, two VHT-LTFs, modulation known after VHT-SIG-B), 0 for an invalid MCS.
-__device__ int parse_vhta(const uint8_t *b, ModS *m)
+__device__ __forceinline__ int parse_vhta(SigBits b, ModS *m)
 {
     int gid = 0, nsts = 0, mcs = 0;
     for (int i = 0; i < 6; i++) gid |= b[i + 4] << i;
@@ -295,7 +301,7 @@ __device__ int parse_vhta(const uint8_t *b, ModS *m)
     return set_vht_mcs(mcs, m) ? 1 : 0;
 }
 // lib/cloud80211phy.cc:1184-1192: VHT-SIG-B of an MU frame, 16 bits of length and 4 bits of MCS.
-__device__ bool parse_vhtb_mu(const uint8_t *b, ModS *m)
+__device__ __forceinline__ bool parse_vhtb_mu(SigBits b, ModS *m)
 {
     int l = 0, mcs = 0;
     for (int i = 0; i < 16; i++) l |= b[i] << i;
@@ -307,7 +313,7 @@ __device__ bool parse_vhtb_mu(const uint8_t *b, ModS *m)
     return true;
 }
 // lib/cloud80211phy.cc:1180-1223, single-user branch
-__device__ void parse_vhtb(const uint8_t *b, ModS *m)
+__device__ __forceinline__ void parse_vhtb(SigBits b, ModS *m)
 {
     if ((b[17] + b[18] + b[19]) == 3) {
         int l = 0;
@@ -379,7 +385,6 @@ __global__ __launch_bounds__(64) void k_preamble(const c32 *__restrict__ iq0, co
     const int bin = brev6(lane);
 
     __shared__ float s_llr[2][96];
-    __shared__ uint8_t s_bits[48];
     __shared__ ModS s_m;
     __shared__ int s_ctl[8];  // 0 status, 1 lsig_mcs, 2 lsig_len, 3 nsamp, 4 fmt, 5 trellis, 6 data_off, 7 MU frame
     __shared__ float s_snr[2];
@@ -457,10 +462,10 @@ __global__ __launch_bounds__(64) void k_preamble(const c32 *__restrict__ iq0, co
         const c32 ps = cconj(cadd(cadd(csub(e7, e21), e43), e57));
         const float pa = cabs32(ps);
         if (demap >= 0) s_llr[0][demap] = cdivf(cmul(e, ps), pa).x;
-        wave_sig_viterbi(s_llr[0], 24, s_bits, lane);
+        const SigBits lsig = {wave_sig_viterbi(s_llr[0], 24, lane)};
         if (lane == 0) {
             int mcs = 0, len = 0, ndbps = 24;
-            if (!check_legacy(s_bits, &mcs, &len, &ndbps)) {
+            if (!check_legacy(lsig, &mcs, &len, &ndbps)) {
                 s_ctl[0] = GR80211_ST_DROP_LSIG;
             } else {
                 s_ctl[1] = mcs;
@@ -494,11 +499,11 @@ __global__ __launch_bounds__(64) void k_preamble(const c32 *__restrict__ iq0, co
             s_llr[1][demap] = m1.y;       // HT-SIG: QBPSK twice
             s_llr[1][demap + 48] = m2.y;
         }
-        wave_sig_viterbi(s_llr[0], 48, s_bits, lane);
+        const SigBits siga = {wave_sig_viterbi(s_llr[0], 48, lane)};
         if (lane == 0) {
-            if (check_vhta(s_bits)) {
+            if (check_vhta(siga)) {
                 s_ctl[4] = GR80211_F_VHT;
-                const int kind = parse_vhta(s_bits, &s_m);
+                const int kind = parse_vhta(siga, &s_m);
                 s_ctl[7] = kind == 2;
                 // MU frames are the one-antenna block's business (lib/demod_impl.cc:347-379); demod2 has no such branch
                 if (kind == 0 || (kind == 2 && two_ant)) s_ctl[0] = GR80211_ST_DROP_UNSUPPORTED;
@@ -509,11 +514,11 @@ __global__ __launch_bounds__(64) void k_preamble(const c32 *__restrict__ iq0, co
         __syncthreads();
         if (s_ctl[0] != GR80211_ST_OK) goto finish;
         if (s_ctl[4] == -1) {
-            wave_sig_viterbi(s_llr[1], 48, s_bits, lane);
+            const SigBits htsig = {wave_sig_viterbi(s_llr[1], 48, lane)};
             if (lane == 0) {
-                if (check_ht(s_bits)) {
+                if (check_ht(htsig)) {
                     s_ctl[4] = GR80211_F_HT;
-                    parse_ht(s_bits, &s_m);
+                    parse_ht(htsig, &s_m);
                 } else {
                     s_ctl[4] = GR80211_F_L;
                 }
@@ -655,16 +660,16 @@ __global__ __launch_bounds__(64) void k_preamble(const c32 *__restrict__ iq0, co
                 inted = (q0.x + q1.x) / 2.0f;
             }
             if (jn >= 0) s_llr[0][c_tab.deint_nl[0][jn]] = inted;
-            wave_sig_viterbi(s_llr[0], 26, s_bits, lane);
+            const SigBits sigb = {wave_sig_viterbi(s_llr[0], 26, lane)};
             // per-stream SNR from the re-encoded SIG-B (float64 accumulation as in the reference)
             double n0 = 0.0, n1 = 0.0;
             if (jn >= 0) {
                 const int k = c_tab.deint_nl[0][jn];  // coded bit carried by this tone
                 const int i = k >> 1;
-                int st = 0;
-                for (int m2 = 0; m2 < 7; m2++)
-                    if (i - m2 >= 0 && s_bits[i - m2]) st |= 1 << m2;
-                const int cb = (k & 1) ? parity7(st & 0117) : parity7(st & 0155);
+                // the encoder's seven-bit window ending at input bit i (bits before the first read as 0), oldest bit
+                // lowest: the generators 0155 / 0117, which count the newest bit lowest, turn into 0133 / 0171
+                const unsigned win = (unsigned)((sigb.w << 6) >> i) & 0x7Fu;
+                const int cb = (k & 1) ? parity7(win & 0171) : parity7(win & 0133);
                 const float ref = cb ? 1.0f : -1.0f;
                 const c32 r0 = mk(q0.x - ref, q0.y - 0.0f);
                 n0 = (double)(r0.x * r0.x + r0.y * r0.y);
@@ -694,8 +699,8 @@ __global__ __launch_bounds__(64) void k_preamble(const c32 *__restrict__ iq0, co
             }
             if (lane == 0) {
                 bool known = true;
-                if (mu) known = parse_vhtb_mu(s_bits, &s_m);
-                else parse_vhtb(s_bits, &s_m);
+                if (mu) known = parse_vhtb_mu(sigb, &s_m);
+                else parse_vhtb(sigb, &s_m);
                 const ModS m = s_m;
                 if (!known) {
                     s_ctl[0] = GR80211_ST_DROP_UNSUPPORTED;
