@@ -36,8 +36,17 @@ int upload_tables(const Tables &t)
 // =========================================================================================
 
 // 64-point forward DFT across the lanes of one wavefront (radix-2 decimation in frequency).
-// Lane l enters with x[l] and leaves with X[brev6(l)].
-__device__ __forceinline__ c32 wave_fft64(c32 x, int lane)
+// Lane l enters with x[l] and leaves with X[brev6(l)].  tw: the lane's twiddle of each of the first five stages
+// (fft_twiddles), fetched once per kernel instead of once per transform.
+__device__ __forceinline__ void fft_twiddles(c32 (&tw)[5], int lane)
+{
+#pragma unroll
+    for (int s = 0; s < 5; s++) {
+        const int k = (lane & ((32 >> s) - 1)) << s;
+        tw[s] = mk(c_tab.tw_re[k], c_tab.tw_im[k]);
+    }
+}
+__device__ __forceinline__ c32 wave_fft64_tw(c32 x, int lane, const c32 (&tw)[5])
 {
 #pragma unroll
     for (int s = 0; s < 6; s++) {
@@ -47,10 +56,7 @@ __device__ __forceinline__ c32 wave_fft64(c32 x, int lane)
         c32 lo = up ? o : x;
         c32 hi = up ? x : o;
         c32 sum = cadd(lo, hi), dif = csub(lo, hi);
-        if (s < 5) {
-            const int k = (lane & (half - 1)) << s;
-            dif = cmul(dif, mk(c_tab.tw_re[k], c_tab.tw_im[k]));
-        }
+        if (s < 5) dif = cmul(dif, tw[s]);
         x = up ? dif : sum;
     }
     return x;
@@ -406,6 +412,8 @@ __global__ __launch_bounds__(64) void k_preamble(const c32 *__restrict__ iq0, co
     }
     __syncthreads();
 
+    c32 tw[5];
+    fft_twiddles(tw, lane);
     const float ltfl = c_tab.ltf_l[bin];
     const float ltfn = c_tab.ltf_nl[bin];
     const bool lused = ltfl != 0.0f;
@@ -452,7 +460,7 @@ __global__ __launch_bounds__(64) void k_preamble(const c32 *__restrict__ iq0, co
             sincosf((lane + SHIFT + 144) * rad, &sn, &cs);
             xs = cmul(xs, mk(cs, sn));
         }
-        const c32 S1 = wave_fft64(x1, lane), S2 = wave_fft64(x2, lane), SG = wave_fft64(xs, lane);
+        const c32 S1 = wave_fft64_tw(x1, lane, tw), S2 = wave_fft64_tw(x2, lane, tw), SG = wave_fft64_tw(xs, lane, tw);
         c32 e = mk(0.0f, 0.0f);
         if (lused) {
             hl = cdivf(cadd(S1, S2), ltfl * 2.0f);
@@ -482,8 +490,8 @@ __global__ __launch_bounds__(64) void k_preamble(const c32 *__restrict__ iq0, co
 
     // ---- format detection (lib/demod_impl.cc:106-148, lib/cloud80211phy.cc:629-648)
     if (s_ctl[1] == 0) {
-        const c32 F1 = wave_fft64(load_samp(in0, SHIFT + lane, nvalid, rad), lane);
-        const c32 F2 = wave_fft64(load_samp(in0, 80 + SHIFT + lane, nvalid, rad), lane);
+        const c32 F1 = wave_fft64_tw(load_samp(in0, SHIFT + lane, nvalid, rad), lane, tw);
+        const c32 F2 = wave_fft64_tw(load_samp(in0, 80 + SHIFT + lane, nvalid, rad), lane, tw);
         c32 e1 = mk(0.0f, 0.0f), e2 = mk(0.0f, 0.0f);
         if (lused) {
             e1 = cdiv(F1, hl);
@@ -561,8 +569,8 @@ __global__ __launch_bounds__(64) void k_preamble(const c32 *__restrict__ iq0, co
         if (mu) {
             // this station's stream out of the two VHT-LTFs of a two-user MU frame (lib/demod_impl.cc:347-379);
             // the second LTF's sequence has its pilot tones negated (LTF_NL_28_F_FLOAT_VHT22)
-            const c32 F1 = wave_fft64(load_samp(in0, off + SHIFT + lane, nvalid, rad), lane);
-            const c32 F2 = wave_fft64(load_samp(in0, off + 80 + SHIFT + lane, nvalid, rad), lane);
+            const c32 F1 = wave_fft64_tw(load_samp(in0, off + SHIFT + lane, nvalid, rad), lane, tw);
+            const c32 F2 = wave_fft64_tw(load_samp(in0, off + 80 + SHIFT + lane, nvalid, rad), lane, tw);
             if (nused) {
                 if (d.mu_pos == 0) hn = cdivf(csub(F1, F2), ltfn * 2.0f);
                 else hn = cdivf(cadd(cdivf(F1, ltfn), cdivf(F2, is_pilot_bin(bin) ? -ltfn : ltfn)), 2.0f);
@@ -570,15 +578,15 @@ __global__ __launch_bounds__(64) void k_preamble(const c32 *__restrict__ iq0, co
             chan1[(size_t)f * 64 + bin] = hn;
         } else if (nss == 1) {
             // lib/demod_impl.cc:380-392
-            const c32 F1 = wave_fft64(load_samp(in0, off + SHIFT + lane, nvalid, rad), lane);
+            const c32 F1 = wave_fft64_tw(load_samp(in0, off + SHIFT + lane, nvalid, rad), lane, tw);
             if (nused) hn = cdivf(F1, ltfn);
             chan1[(size_t)f * 64 + bin] = hn;
         } else {
             // lib/demod2_impl.cc:372-463
-            const c32 F1 = wave_fft64(load_samp(in0, off + SHIFT + lane, nvalid, rad), lane);
-            const c32 F2 = wave_fft64(load_samp(in1, off + SHIFT + lane, nvalid, rad), lane);
-            const c32 F12 = wave_fft64(load_samp(in0, off + 80 + SHIFT + lane, nvalid, rad), lane);
-            const c32 F22 = wave_fft64(load_samp(in1, off + 80 + SHIFT + lane, nvalid, rad), lane);
+            const c32 F1 = wave_fft64_tw(load_samp(in0, off + SHIFT + lane, nvalid, rad), lane, tw);
+            const c32 F2 = wave_fft64_tw(load_samp(in1, off + SHIFT + lane, nvalid, rad), lane, tw);
+            const c32 F12 = wave_fft64_tw(load_samp(in0, off + 80 + SHIFT + lane, nvalid, rad), lane, tw);
+            const c32 F22 = wave_fft64_tw(load_samp(in1, off + 80 + SHIFT + lane, nvalid, rad), lane, tw);
             const float l2 = ltfn * 0.5f;
             h[0] = cmulf(csub(F1, F12), l2);
             h[1] = cmulf(csub(F2, F22), l2);
@@ -632,7 +640,7 @@ __global__ __launch_bounds__(64) void k_preamble(const c32 *__restrict__ iq0, co
             const int jn = c_tab.data_idx_nl[bin];
             float inted = 0.0f;
             if (nss == 1) {
-                const c32 F1 = wave_fft64(load_samp(in0, ob + SHIFT + lane, nvalid, rad), lane);
+                const c32 F1 = wave_fft64_tw(load_samp(in0, ob + SHIFT + lane, nvalid, rad), lane, tw);
                 c32 e = mk(0.0f, 0.0f);
                 if (nused) e = cdiv(F1, hn);
                 const c32 ps = cconj(cadd(cadd(csub(lane_c<LN7>(e), lane_c<LN21>(e)), lane_c<LN43>(e)), lane_c<LN57>(e)));
@@ -640,8 +648,8 @@ __global__ __launch_bounds__(64) void k_preamble(const c32 *__restrict__ iq0, co
                 q0 = cdivf(cmul(e, ps), pa);
                 inted = q0.x;
             } else {
-                const c32 F1 = wave_fft64(load_samp(in0, ob + SHIFT + lane, nvalid, rad), lane);
-                const c32 F2 = wave_fft64(load_samp(in1, ob + SHIFT + lane, nvalid, rad), lane);
+                const c32 F1 = wave_fft64_tw(load_samp(in0, ob + SHIFT + lane, nvalid, rad), lane, tw);
+                const c32 F2 = wave_fft64_tw(load_samp(in1, ob + SHIFT + lane, nvalid, rad), lane, tw);
                 c32 s1, s2;
                 zf2(F1, F2, h, hi, s1, s2);
                 const c32 u1 = cmul(s1, pl1), u2 = cmul(s2, pl2);  // meaningful on pilot lanes
@@ -1113,22 +1121,6 @@ __device__ __forceinline__ c32 derot(int k, float rad)
     return mk(cs, sn);
 }
 
-// 64-point DFT as wave_fft64, with this lane's five twiddles handed in (they do not change from symbol to symbol).
-__device__ __forceinline__ c32 wave_fft64_tw(c32 x, int lane, const c32 (&tw)[5])
-{
-#pragma unroll
-    for (int s = 0; s < 6; s++) {
-        const int half = 32 >> s;
-        c32 o = mk(__shfl_xor(x.x, half), __shfl_xor(x.y, half));
-        const bool up = (lane & half) != 0;
-        c32 lo = up ? o : x;
-        c32 hi = up ? x : o;
-        c32 sum = cadd(lo, hi), dif = csub(lo, hi);
-        if (s < 5) dif = cmul(dif, tw[s]);
-        x = up ? dif : sum;
-    }
-    return x;
-}
 
 // One workgroup per frame; the instantiation for the frame's number of spatial streams does the work, the other
 // one leaves at once (two kernels keep the one-stream path's registers, and with them its occupancy, free of the
@@ -1179,11 +1171,7 @@ __global__ __launch_bounds__(64 * DEMOD_WAVES) void k_demod(const c32 *__restric
     // what does not change from symbol to symbol sits in registers before the loop starts: the twiddles, and
     // the 127 pilot polarities spread over the lanes (lane l holds entries l and 64 + l)
     c32 tw[5];
-#pragma unroll
-    for (int s = 0; s < 5; s++) {
-        const int k = (lane & ((32 >> s) - 1)) << s;
-        tw[s] = mk(c_tab.tw_re[k], c_tab.tw_im[k]);
-    }
+    fft_twiddles(tw, lane);
     const float pol0 = c_tab.pilot_p[lane], pol1 = c_tab.pilot_p[lane < 63 ? 64 + lane : 64];
     asm volatile("; loop invariants resident" ::"v"(tw[0].x), "v"(tw[0].y), "v"(tw[1].x), "v"(tw[1].y), "v"(tw[2].x),
                  "v"(tw[2].y), "v"(tw[3].x), "v"(tw[3].y), "v"(tw[4].x), "v"(tw[4].y), "v"(pol0), "v"(pol1));
