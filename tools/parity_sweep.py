@@ -41,7 +41,8 @@ def main():
     kinds = [(0, m, 1) for m in range(8)] + [(1, m, 1) for m in range(8)] + [(2, m, 1) for m in range(10)] + \
             [(1, m, 2) for m in range(8, 16)] + [(2, m, 2) for m in range(10)]
     t0 = time.time()
-    counts = {"frames": 0, "status_ok": 0, "fcs_ok": 0, "llr_checked": 0, "ill_conditioned_symbols": 0, "differences": 0}
+    counts = {"frames": 0, "status_ok": 0, "fcs_ok": 0, "llr_checked": 0, "ill_conditioned_symbols": 0, "of_them_in_long_gi_frames": 0,
+              "differences": 0}
     worst_llr = 0.0
     for two_ant in (False, True):
         pool = [k for k in kinds if k[2] == 1] if not two_ant else kinds
@@ -117,6 +118,7 @@ def main():
                         # is turned by, is small: there the comparison is only as good as that sum's conditioning
                         explained = bool(np.all(sens[over] >= 0.5 * per[over])) or meta[i][2]
                         counts["ill_conditioned_symbols"] += int(over.sum()) if explained else 0
+                        counts["of_them_in_long_gi_frames"] += int(over.sum()) if explained and not meta[i][2] else 0
                         print("frame %d (%d antennas%s): symbols %s beyond tolerance by up to %.3g; the oracle moves them by "
                               "up to %.3g under a one-ulp change of the input: %s" %
                               (i, 2 if two_ant else 1, ", short GI" if meta[i][2] else "", np.nonzero(over)[0].tolist(),
