@@ -161,22 +161,25 @@ class StreamBlock:
         self._check(self.lib.gr80211_block_flush(self.h), "flush")
 
     def run(self, streams, tags=(), chunk=4096, noutput_items=8192):
+        """Feeds whole streams through work() in windows of `chunk` items with room for `noutput_items` on every output;
+        either may be a callable that names the next call's size (a scheduler's windows vary from call to call)."""
         streams = [np.ascontiguousarray(s) for s in streams]
         n = min(len(s) for s in streams)
         tags = sorted(tags, key=lambda t: (t[1], t[0]))
-        at, idle = 0, 0
+        at, idle, grow = 0, 0, 1
+        nout = noutput_items if callable(noutput_items) else (lambda: noutput_items)
         while at < n:
-            win = min(chunk, n - at)
-            got = self.work([s[at:at + win] for s in streams], [t for t in tags if at <= t[0] < at + win], noutput_items)
+            win = min((chunk() if callable(chunk) else chunk) * grow, n - at)
+            got = self.work([s[at:at + win] for s in streams], [t for t in tags if at <= t[0] < at + win], nout())
             # tags of items not consumed are handed over again with the next window, like a scheduler's tag store
             at += got
             if got == 0:
                 idle += 1
                 if win == n - at or idle > 4:
                     break
-                chunk *= 2
+                grow *= 2
             else:
-                idle = 0
+                idle, grow = 0, 1
         self.flush()
-        self.drain(noutput_items)
+        self.drain(nout())
         return self.msgs
