@@ -3,6 +3,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <utility>
 #include <string>
 
 #include "detect_kernels.h"
@@ -34,6 +35,7 @@ struct gr80211_ctx {
     // frame detection
     Buf det_mask, det_blk, det_runs, det_rec, det_totals_d, cap_desc, cap_ws;
     Buf tx_desc, sig_desc, chanl, out_off;
+    Buf info_alt, chan1_alt, chan2_alt;  // the capture path's second set of frame records and channels
     uint32_t *det_totals_h = nullptr;  // pinned
     SchedTotals *totals_h = nullptr;  // pinned
     int ampdu_strict = 0;  // de-aggregate A-MPDUs by the standard's rules instead of the reference's
@@ -337,7 +339,8 @@ void gr80211_destroy(gr80211_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (Buf *b : {&c->desc, &c->ddesc, &c->info, &c->chan1, &c->chan2, &c->llr, &c->slot_frame, &c->groups, &c->dec,
                    &c->bitsw, &c->totals_d, &c->sched_ws, &c->blk_llr, &c->det_mask, &c->det_blk, &c->det_runs,
-                   &c->det_rec, &c->det_totals_d, &c->cap_desc, &c->cap_ws, &c->tx_desc, &c->sig_desc, &c->chanl, &c->out_off})
+                   &c->det_rec, &c->det_totals_d, &c->cap_desc, &c->cap_ws, &c->tx_desc, &c->sig_desc, &c->chanl, &c->out_off,
+                   &c->info_alt, &c->chan1_alt, &c->chan2_alt})
         release(*b);
     if (c->totals_h) (void)hipHostFree(c->totals_h);
     if (c->det_totals_h) (void)hipHostFree(c->det_totals_h);
@@ -437,8 +440,18 @@ int gr80211_rx_capture(gr80211_ctx *c, const void *d_iq0, const void *d_iq1, uin
     if (nf == 0) return GR80211_OK;
     if (d_desc_out)
         HIP_TRY(c, hipMemcpyAsync(d_desc_out, d_sel, (size_t)nf * sizeof(gr80211_frame_desc), hipMemcpyDeviceToDevice, s));
-    if ((rc = front_end(c, s, d_iq0, d_iq1, n_samples, d_sel, nf, GR80211_FLAG_DESC_ON_DEVICE, &dd))) return rc;
-    rc = run_decode_stages(c, s, nf, true, d_iq0, d_iq1, n_samples, dd, nullptr, d_out, out_stride, d_out_len, d_n_pdu, nullptr, 0,
+    // the preamble has run over these frames already (a frame's span does not change what it finds): their records
+    // and channels move to the front of a second set of buffers, which then takes the first set's place
+    if ((rc = ensure(c, c->info_alt, (size_t)nf * sizeof(gr80211_frame_info)))) return rc;
+    if ((rc = ensure(c, c->chan1_alt, (size_t)nf * 64 * 8))) return rc;
+    if (d_iq1 && (rc = ensure(c, c->chan2_alt, (size_t)nf * 520 * 8))) return rc;
+    launch_pre_gather(path, nf, (const gr80211_frame_info *)c->info.p, c->chan1.p, d_iq1 ? c->chan2.p : nullptr,
+                      (gr80211_frame_info *)c->info_alt.p, c->chan1_alt.p, c->chan2_alt.p, s);
+    std::swap(c->info, c->info_alt);
+    std::swap(c->chan1, c->chan1_alt);
+    if (d_iq1) std::swap(c->chan2, c->chan2_alt);
+    mark(c, 1, s);
+    rc = run_decode_stages(c, s, nf, true, d_iq0, d_iq1, n_samples, d_sel, nullptr, d_out, out_stride, d_out_len, d_n_pdu, nullptr, 0,
                            true, nullptr, nullptr);
     if (rc) return rc;
     return finish_timing(c, s);

@@ -43,6 +43,8 @@ void launch_desc_to_info(const gr80211_dec_desc *desc, int n, uint64_t llr_float
 void launch_schedule(gr80211_frame_info *info, int n, int assign_llr, int32_t *slot_frame, int slot_cap,
                      GroupInfo *groups, int group_cap, SchedTotals *totals, uint32_t *ws, unsigned long long *blk_llr,
                      hipStream_t s);
+void launch_pre_gather(const int32_t *path, int n, const gr80211_frame_info *info_in, const void *chan1_in,
+                       const void *chan2_in, gr80211_frame_info *info_out, void *chan1_out, void *chan2_out, hipStream_t s);
 void launch_demod(const void *iq0, const void *iq1, uint64_t arena_len, const gr80211_frame_desc *desc, int n,
                   const gr80211_frame_info *info, const void *chan1, const void *chan2, float *llr,
                   hipStream_t s);

@@ -1913,6 +1913,24 @@ __global__ __launch_bounds__(256) void k_signal_copy(const c32 *__restrict__ iq0
     }
 }
 
+// What k_preamble left for the frames path[0..n) names, moved to places 0..n-1 of a second set of buffers: the
+// capture path runs the preamble over every sync byte to learn the frames' spans, then goes on with the frames
+// `signal` would deal with, whose records and channels it already has.  One wave per frame.
+__global__ __launch_bounds__(64) void k_pre_gather(const int32_t *__restrict__ path, int n,
+                                                   const gr80211_frame_info *__restrict__ info_in,
+                                                   const c32 *__restrict__ chan1_in, const c32 *__restrict__ chan2_in,
+                                                   gr80211_frame_info *__restrict__ info_out, c32 *__restrict__ chan1_out,
+                                                   c32 *__restrict__ chan2_out)
+{
+    const int m = blockIdx.x;
+    if (m >= n) return;
+    const int i = path[m], lane = threadIdx.x;
+    if (lane == 0) info_out[m] = info_in[i];
+    chan1_out[(size_t)m * 64 + lane] = chan1_in[(size_t)i * 64 + lane];
+    if (chan2_in)
+        for (int k = lane; k < CH2; k += 64) chan2_out[(size_t)m * CH2 + k] = chan2_in[(size_t)i * CH2 + k];
+}
+
 __global__ void k_clear_outputs(int32_t *a, int32_t *b, int n)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2002,6 +2020,12 @@ void launch_ndp_emit(const void *iq0, uint64_t arena_len, const gr80211_frame_de
 {
     hipLaunchKernelGGL(k_ndp_emit, dim3((n + 3) / 4), dim3(256), 0, s, (const c32 *)iq0, arena_len, desc, n, info, out, out_stride,
                        out_len, n_pdu);
+}
+void launch_pre_gather(const int32_t *path, int n, const gr80211_frame_info *info_in, const void *chan1_in,
+                       const void *chan2_in, gr80211_frame_info *info_out, void *chan1_out, void *chan2_out, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_pre_gather, dim3(n), dim3(64), 0, s, path, n, info_in, (const c32 *)chan1_in, (const c32 *)chan2_in,
+                       info_out, (c32 *)chan1_out, (c32 *)chan2_out);
 }
 void launch_clear_outputs(int32_t *out_len, int32_t *n_pdu, int n, hipStream_t s)
 {
