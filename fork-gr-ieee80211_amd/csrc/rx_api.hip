@@ -36,6 +36,15 @@ struct gr80211_ctx {
     Buf det_mask, det_blk, det_runs, det_rec, det_totals_d, cap_desc, cap_ws;
     Buf tx_desc, sig_desc, chanl, out_off;
     Buf info_alt, chan1_alt, chan2_alt;  // the capture path's second set of frame records and channels
+    // a batch between gr80211_rx_submit and gr80211_rx_finish
+    struct {
+        bool active;
+        int n;
+        const void *iq0, *iq1;
+        uint64_t arena_len;
+        const gr80211_frame_desc *desc;
+        hipStream_t stream;
+    } pending = {};
     uint32_t *det_totals_h = nullptr;  // pinned
     SchedTotals *totals_h = nullptr;  // pinned
     int ampdu_strict = 0;  // de-aggregate A-MPDUs by the standard's rules instead of the reference's
@@ -127,11 +136,8 @@ int finish_timing(gr80211_ctx *c, hipStream_t s)
     return GR80211_OK;
 }
 
-// Shared tail: schedule -> (demod) -> viterbi -> traceback.
-int run_decode_stages(gr80211_ctx *c, hipStream_t s, int n, bool from_iq, const void *d_iq0, const void *d_iq1,
-                      uint64_t arena_len, const gr80211_frame_desc *d_desc, const float *d_llr_in, uint8_t *d_out, int out_stride,
-                      int32_t *d_out_len, int32_t *d_n_pdu, uint8_t *d_bits, int bits_stride, bool decode,
-                      const float **llr_used, uint64_t *llr_floats)
+// Shared tail, first half: the scheduler's kernels and the copy of its totals to the host, all asynchronous.
+int launch_sched_stage(gr80211_ctx *c, hipStream_t s, int n, bool from_iq)
 {
     const int slot_cap = n + 4 * 64 + 64;
     const int group_cap = slot_cap / 64 + 1;
@@ -148,6 +154,18 @@ int run_decode_stages(gr80211_ctx *c, hipStream_t s, int n, bool from_iq, const 
                     (unsigned long long *)c->blk_llr.p, s);
     mark(c, 2, s);
     HIP_TRY(c, hipMemcpyAsync(c->totals_h, c->totals_d.p, sizeof(SchedTotals), hipMemcpyDeviceToHost, s));
+    return GR80211_OK;
+}
+
+// Shared tail, second half: waits for the scheduler's totals (they size the work buffers), then (demod) -> viterbi ->
+// traceback.
+int finish_decode_stages(gr80211_ctx *c, hipStream_t s, int n, bool from_iq, const void *d_iq0, const void *d_iq1,
+                         uint64_t arena_len, const gr80211_frame_desc *d_desc, const float *d_llr_in, uint8_t *d_out,
+                         int out_stride, int32_t *d_out_len, int32_t *d_n_pdu, uint8_t *d_bits, int bits_stride, bool decode,
+                         const float **llr_used, uint64_t *llr_floats)
+{
+    int rc;
+    gr80211_frame_info *info = (gr80211_frame_info *)c->info.p;
     HIP_TRY(c, hipStreamSynchronize(s));
     const SchedTotals tot = *c->totals_h;
     if (tot.n_groups < 0) return fail(c, GR80211_ERR_ARG, "scheduler capacity exceeded");
@@ -200,6 +218,18 @@ int run_decode_stages(gr80211_ctx *c, hipStream_t s, int n, bool from_iq, const 
     mark(c, 5, s);
     HIP_TRY(c, hipGetLastError());
     return GR80211_OK;
+}
+
+// Shared tail: schedule -> (demod) -> viterbi -> traceback.
+int run_decode_stages(gr80211_ctx *c, hipStream_t s, int n, bool from_iq, const void *d_iq0, const void *d_iq1,
+                      uint64_t arena_len, const gr80211_frame_desc *d_desc, const float *d_llr_in, uint8_t *d_out, int out_stride,
+                      int32_t *d_out_len, int32_t *d_n_pdu, uint8_t *d_bits, int bits_stride, bool decode,
+                      const float **llr_used, uint64_t *llr_floats)
+{
+    int rc = launch_sched_stage(c, s, n, from_iq);
+    if (rc) return rc;
+    return finish_decode_stages(c, s, n, from_iq, d_iq0, d_iq1, arena_len, d_desc, d_llr_in, d_out, out_stride, d_out_len,
+                                d_n_pdu, d_bits, bits_stride, decode, llr_used, llr_floats);
 }
 
 int stage_desc(gr80211_ctx *c, hipStream_t s, const void *desc, size_t bytes, unsigned flags, Buf &dst, const void **out)
@@ -380,6 +410,42 @@ int gr80211_rx_batch(gr80211_ctx *c, const void *d_iq0, const void *d_iq1, uint6
     if (d_info)
         HIP_TRY(c, hipMemcpyAsync(d_info, c->info.p, (size_t)n * sizeof(gr80211_frame_info), hipMemcpyDeviceToDevice, s));
     return finish_timing(c, s);
+}
+
+int gr80211_rx_submit(gr80211_ctx *c, const void *d_iq0, const void *d_iq1, uint64_t arena_len,
+                      const gr80211_frame_desc *desc, int n, unsigned flags, void *stream)
+{
+    if (!c) return GR80211_ERR_ARG;
+    if (c->pending.active) return fail(c, GR80211_ERR_ARG, "gr80211_rx_submit: the batch submitted before has not been finished");
+    if (!d_iq0 || !desc || n < 0) return fail(c, GR80211_ERR_ARG, "gr80211_rx_submit: bad argument");
+    if (n > (1 << 20)) return fail(c, GR80211_ERR_ARG, "gr80211_rx_submit: at most 1048576 frames per call");
+    c->pending = {true, n, d_iq0, d_iq1, arena_len, nullptr, nullptr};
+    if (n == 0) return GR80211_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = pick(c, stream);
+    c->pending.stream = s;
+    int rc = front_end(c, s, d_iq0, d_iq1, arena_len, desc, n, flags, &c->pending.desc);
+    if (!rc) rc = launch_sched_stage(c, s, n, true);
+    if (rc) c->pending.active = false;
+    return rc;
+}
+
+int gr80211_rx_finish(gr80211_ctx *c, uint8_t *d_out, int out_stride, int32_t *d_out_len, int32_t *d_n_pdu,
+                      gr80211_frame_info *d_info)
+{
+    if (!c) return GR80211_ERR_ARG;
+    if (!c->pending.active) return fail(c, GR80211_ERR_ARG, "gr80211_rx_finish: no batch has been submitted");
+    const auto p = c->pending;
+    c->pending.active = false;
+    if (p.n == 0) return GR80211_OK;
+    if (!d_out || !d_out_len || !d_n_pdu || out_stride < 8) return fail(c, GR80211_ERR_ARG, "gr80211_rx_finish: bad argument");
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc = finish_decode_stages(c, p.stream, p.n, true, p.iq0, p.iq1, p.arena_len, p.desc, nullptr, d_out, out_stride, d_out_len,
+                                  d_n_pdu, nullptr, 0, true, nullptr, nullptr);
+    if (rc) return rc;
+    if (d_info)
+        HIP_TRY(c, hipMemcpyAsync(d_info, c->info.p, (size_t)p.n * sizeof(gr80211_frame_info), hipMemcpyDeviceToDevice, p.stream));
+    return finish_timing(c, p.stream);
 }
 
 int gr80211_detect(gr80211_ctx *c, const void *d_iq, uint64_t n_samples, gr80211_frame_desc *d_desc, int max_desc,

@@ -71,6 +71,7 @@ EXPORTS = [
     "gr80211_copy_h2d", "gr80211_copy_d2h", "gr80211_set_profiling", "gr80211_last_timing",
     "gr80211_version", "gr80211_table_checksum", "gr80211_tx_samples", "gr80211_tx_batch", "gr80211_set_mu_pos", "gr80211_set_ampdu_strict", "gr80211_tx_mu_batch",
     "gr80211_host_alloc", "gr80211_host_free", "gr80211_copy_d2d", "gr80211_signal_emit_batch", "gr80211_demod_tagged_batch",
+    "gr80211_rx_submit", "gr80211_rx_finish",
 ]
 
 _lib = None
@@ -95,6 +96,8 @@ def load_library():
     L.gr80211_last_error.restype = C.c_char_p
     L.gr80211_sync.argtypes = [vp, vp]
     L.gr80211_rx_batch.argtypes = [vp, vp, vp, C.c_uint64, vp, C.c_int, C.c_uint, vp, C.c_int, vp, vp, vp, vp]
+    L.gr80211_rx_submit.argtypes = [vp, vp, vp, C.c_uint64, vp, C.c_int, C.c_uint, vp]
+    L.gr80211_rx_finish.argtypes = [vp, vp, C.c_int, vp, vp, vp]
     L.gr80211_detect.argtypes = [vp, vp, C.c_uint64, vp, C.c_int, C.POINTER(C.c_int), vp]
     L.gr80211_rx_capture.argtypes = [vp, vp, vp, C.c_uint64, vp, C.c_int, vp, vp, C.c_int, vp, C.POINTER(C.c_int), vp]
     L.gr80211_signal_batch.argtypes = [vp, vp, vp, C.c_uint64, vp, C.c_int, C.c_uint, vp, vp]
@@ -261,6 +264,23 @@ class RxContext:
             C.c_void_p(info.data_ptr()) if info is not None else None, self._stream())
         self._check(rc, "gr80211_rx_batch")
         return keep
+
+    def rx_submit(self, iq0, iq1, desc, n_frames):
+        """First half of rx_batch_into: preamble and scheduling are launched, nothing is waited for.  Returns what has
+        to stay alive until rx_finish."""
+        dp, flags, keep = self._desc_arg(desc)
+        rc = self.lib.gr80211_rx_submit(
+            self.h, C.c_void_p(iq0.data_ptr()), C.c_void_p(iq1.data_ptr()) if iq1 is not None else None,
+            iq0.numel(), dp, n_frames, flags, self._stream())
+        self._check(rc, "gr80211_rx_submit")
+        return keep
+
+    def rx_finish(self, out, out_len, n_pdu, info=None):
+        """Second half: waits for the scheduler's totals, launches demodulator and decoder, returns without waiting."""
+        rc = self.lib.gr80211_rx_finish(
+            self.h, C.c_void_p(out.data_ptr()), out.shape[1], C.c_void_p(out_len.data_ptr()),
+            C.c_void_p(n_pdu.data_ptr()), C.c_void_p(info.data_ptr()) if info is not None else None)
+        self._check(rc, "gr80211_rx_finish")
 
     def detect(self, iq, max_desc=None):
         """Frame detection over a capture (complex64 CUDA tensor).  Returns (desc tensor on the device as

@@ -177,6 +177,20 @@ int gr80211_rx_batch(gr80211_ctx *ctx, const void *d_iq0, const void *d_iq1, uin
                      gr80211_frame_info *d_info, void *stream);
 
 /*
+ * gr80211_rx_batch in two calls, for a caller that keeps several contexts busy from one thread (no counterpart in
+ * the reference, where GNU Radio's scheduler runs every block on a thread of its own).  gr80211_rx_submit launches the
+ * preamble and scheduling kernels and returns without waiting; gr80211_rx_finish waits for the scheduler's totals, which
+ * size the work buffers, launches the demodulator and the decoder and returns without waiting for them.  Between the
+ * two calls the context takes no other batch call, and the arena and descriptors must stay as they are until the
+ * stream has run the work of gr80211_rx_finish.  With two contexts: submit(A), submit(B), finish(A), finish(B), and
+ * while A decodes, B's preamble and demodulator fill the SIMDs A leaves idle.  Same results as gr80211_rx_batch.
+ */
+int gr80211_rx_submit(gr80211_ctx *ctx, const void *d_iq0, const void *d_iq1, uint64_t arena_len,
+                      const gr80211_frame_desc *desc, int n_frames, unsigned flags, void *stream);
+int gr80211_rx_finish(gr80211_ctx *ctx, uint8_t *d_out, int out_stride, int32_t *d_out_len, int32_t *d_n_pdu,
+                      gr80211_frame_info *d_info);
+
+/*
  * Frame detection over a whole capture: the work of the blocks upstream of `signal` in the reference's receive
  * flowgraph (examples/rx.grc: presiso -> trigger -> sync; examples/presiso.grc:68-137,218-229,
  * lib/trigger_impl.cc:59-117, lib/sync_impl.cc:61-196).  d_iq: complex64 samples of the (first) antenna.

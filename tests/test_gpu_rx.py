@@ -513,3 +513,51 @@ def test_two_contexts_on_two_threads(pkg, oracle):
         for rep in got[k]:
             assert np.array_equal(rep[0], alone[k][0]) and rep[1] == alone[k][1]
 
+
+def test_submit_and_finish_on_two_contexts_from_one_thread(pkg, oracle):
+    """gr80211_rx_submit / gr80211_rx_finish: two contexts kept busy by one thread (submit A, submit B, finish A,
+    finish B, several rounds) give what gr80211_rx_batch gives; calls out of order are refused and leave the context
+    usable."""
+    import torch
+    tx = pkg.txgen
+    rng = np.random.default_rng(43)
+    jobs = []
+    for k in range(2):
+        frames = [make_noisy(tx, rng, fmt, mcs, 1, int(rng.integers(100, 900)), 33.0)[0]
+                  for fmt, mcs in ((0, 4), (1, 6), (2, 8), (2, 2)) * (5 + 3 * k)]
+        iq0, _, sync, navail = build_arena(frames)
+        jobs.append((torch.from_numpy(iq0).cuda(), pkg.RxContext.make_desc(sync, navail), len(frames)))
+    ctxs = [pkg.RxContext(0), pkg.RxContext(0)]
+    want = []
+    for (d0, desc, n), ctx in zip(jobs, ctxs):
+        res = ctx.rx_batch(d0, None, desc, n)
+        ctx.sync()
+        want.append((res["out_len"].cpu().numpy().copy(), res["n_pdu"].cpu().numpy().copy(), res["out"].cpu().numpy().copy(),
+                     res["info"].cpu().numpy().copy()))
+        assert int(want[-1][1].sum()) == n
+    outs = [(torch.zeros((n, 4104), dtype=torch.uint8, device="cuda"), torch.zeros(n, dtype=torch.int32, device="cuda"),
+             torch.zeros(n, dtype=torch.int32, device="cuda"),
+             torch.zeros(n * pkg.rx.FRAME_INFO_DTYPE.itemsize, dtype=torch.uint8, device="cuda")) for _, _, n in jobs]
+    with pytest.raises(RuntimeError):
+        ctxs[0].rx_finish(*outs[0][:3])                     # nothing submitted
+    for rnd in range(4):
+        keep = [ctx.rx_submit(d0, None, desc, n) for (d0, desc, n), ctx in zip(jobs, ctxs)]
+        if rnd == 1:
+            with pytest.raises(RuntimeError):
+                ctxs[1].rx_submit(jobs[1][0], None, jobs[1][1], jobs[1][2])   # the batch before is not finished
+        for ctx, o in zip(ctxs, outs):
+            ctx.rx_finish(o[0], o[1], o[2], o[3])
+        for ctx in ctxs:
+            ctx.sync()
+        del keep
+        for (ln, npd, out, info), o in zip(want, outs):
+            assert np.array_equal(o[1].cpu().numpy(), ln) and np.array_equal(o[2].cpu().numpy(), npd)
+            got = o[0].cpu().numpy()
+            assert all(bytes(got[i, : ln[i]]) == bytes(out[i, : ln[i]]) for i in range(len(ln)))
+            assert np.array_equal(o[3].cpu().numpy(), info)
+        for o in outs:
+            for t in o:
+                t.zero_()
+    for ctx in ctxs:
+        ctx.close()
+

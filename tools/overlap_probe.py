@@ -25,6 +25,8 @@ def main():
     ap.add_argument("--workload", default="vht_mcs8_1500B_snr30")
     ap.add_argument("--depth", type=int, default=2)
     ap.add_argument("--own-streams", action="store_true", help="every context on the stream it created itself")
+    ap.add_argument("--single-thread", action="store_true",
+                    help="one host thread keeps the contexts busy with gr80211_rx_submit / gr80211_rx_finish")
     args = ap.parse_args()
     import numpy as np
     import torch
@@ -67,12 +69,23 @@ def main():
         for t in o:
             t.zero_()
     torch.cuda.synchronize()
-    threads = [threading.Thread(target=run, args=(k, per)) for k in range(args.depth)]
     t0 = time.perf_counter()
-    for t in threads:
-        t.start()
-    for t in threads:
-        t.join()
+    if args.single_thread:
+        # submit every context's batch, then finish them in the same order; the next round's submits queue behind the
+        # decoders on each context's own stream
+        for _ in range(per):
+            keep = [ctxs[k].rx_submit(arena, arena1, desc, n) for k in range(args.depth)]
+            for k in range(args.depth):
+                ctxs[k].rx_finish(*outs[k])
+            del keep
+        for c in ctxs:
+            c.sync()
+    else:
+        threads = [threading.Thread(target=run, args=(k, per)) for k in range(args.depth)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
     torch.cuda.synchronize()
     ovl = time.perf_counter() - t0
     ok = []
