@@ -139,6 +139,7 @@ int finish_timing(gr80211_ctx *c, hipStream_t s)
 // Shared tail, first half: the scheduler's kernels and the copy of its totals to the host, all asynchronous.
 int launch_sched_stage(gr80211_ctx *c, hipStream_t s, int n, bool from_iq)
 {
+    if (c->pending.active) return fail(c, GR80211_ERR_ARG, "a batch submitted with gr80211_rx_submit is waiting for gr80211_rx_finish");
     const int slot_cap = n + 4 * 64 + 64;
     const int group_cap = slot_cap / 64 + 1;
     int rc;
@@ -251,6 +252,7 @@ int front_end(gr80211_ctx *c, hipStream_t s, const void *d_iq0, const void *d_iq
 {
     int rc;
     const void *dd = nullptr;
+    if (c->pending.active) return fail(c, GR80211_ERR_ARG, "a batch submitted with gr80211_rx_submit is waiting for gr80211_rx_finish");
     if ((rc = stage_desc(c, s, desc, (size_t)n * sizeof(gr80211_frame_desc), flags, c->desc, &dd))) return rc;
     if ((rc = ensure(c, c->info, (size_t)n * sizeof(gr80211_frame_info)))) return rc;
     if ((rc = ensure(c, c->chan1, (size_t)n * 64 * 8))) return rc;
@@ -419,15 +421,17 @@ int gr80211_rx_submit(gr80211_ctx *c, const void *d_iq0, const void *d_iq1, uint
     if (c->pending.active) return fail(c, GR80211_ERR_ARG, "gr80211_rx_submit: the batch submitted before has not been finished");
     if (!d_iq0 || !desc || n < 0) return fail(c, GR80211_ERR_ARG, "gr80211_rx_submit: bad argument");
     if (n > (1 << 20)) return fail(c, GR80211_ERR_ARG, "gr80211_rx_submit: at most 1048576 frames per call");
-    c->pending = {true, n, d_iq0, d_iq1, arena_len, nullptr, nullptr};
-    if (n == 0) return GR80211_OK;
-    HIP_TRY(c, hipSetDevice(c->device));
-    hipStream_t s = pick(c, stream);
-    c->pending.stream = s;
-    int rc = front_end(c, s, d_iq0, d_iq1, arena_len, desc, n, flags, &c->pending.desc);
-    if (!rc) rc = launch_sched_stage(c, s, n, true);
-    if (rc) c->pending.active = false;
-    return rc;
+    c->pending = {false, n, d_iq0, d_iq1, arena_len, nullptr, nullptr};
+    if (n > 0) {
+        HIP_TRY(c, hipSetDevice(c->device));
+        hipStream_t s = pick(c, stream);
+        c->pending.stream = s;
+        int rc = front_end(c, s, d_iq0, d_iq1, arena_len, desc, n, flags, &c->pending.desc);
+        if (!rc) rc = launch_sched_stage(c, s, n, true);
+        if (rc) return rc;
+    }
+    c->pending.active = true;  // from here to gr80211_rx_finish every other batch call is refused
+    return GR80211_OK;
 }
 
 int gr80211_rx_finish(gr80211_ctx *c, uint8_t *d_out, int out_stride, int32_t *d_out_len, int32_t *d_n_pdu,

@@ -181,7 +181,7 @@ int gr80211_rx_batch(gr80211_ctx *ctx, const void *d_iq0, const void *d_iq1, uin
  * the reference, where GNU Radio's scheduler runs every block on a thread of its own).  gr80211_rx_submit launches the
  * preamble and scheduling kernels and returns without waiting; gr80211_rx_finish waits for the scheduler's totals, which
  * size the work buffers, launches the demodulator and the decoder and returns without waiting for them.  Between the
- * two calls the context takes no other batch call, and the arena and descriptors must stay as they are until the
+ * two calls the context refuses every other batch call, and the arena and descriptors must stay as they are until the
  * stream has run the work of gr80211_rx_finish.  With two contexts: submit(A), submit(B), finish(A), finish(B), and
  * while A decodes, B's preamble and demodulator fill the SIMDs A leaves idle.  Same results as gr80211_rx_batch.
  */

@@ -545,6 +545,8 @@ def test_submit_and_finish_on_two_contexts_from_one_thread(pkg, oracle):
         if rnd == 1:
             with pytest.raises(RuntimeError):
                 ctxs[1].rx_submit(jobs[1][0], None, jobs[1][1], jobs[1][2])   # the batch before is not finished
+            with pytest.raises(RuntimeError):
+                ctxs[1].rx_batch(jobs[1][0], None, jobs[1][1], jobs[1][2])    # nor may another batch call cut in
         for ctx, o in zip(ctxs, outs):
             ctx.rx_finish(o[0], o[1], o[2], o[3])
         for ctx in ctxs:
