@@ -116,6 +116,16 @@ void release(Buf &b)
 
 hipStream_t pick(gr80211_ctx *c, void *stream) { return stream ? (hipStream_t)stream : c->stream; }
 
+// Between gr80211_rx_submit and gr80211_rx_finish the context's workspaces belong to the submitted batch: every other
+// batch entry point checks this before it stages a descriptor, grows a buffer or launches a kernel.
+int refuse_if_pending(gr80211_ctx *c, const char *who)
+{
+    if (!c->pending.active) return GR80211_OK;
+    c->err = who;
+    c->err += ": a batch submitted with gr80211_rx_submit is waiting for gr80211_rx_finish";
+    return GR80211_ERR_ARG;
+}
+
 void mark(gr80211_ctx *c, int i, hipStream_t s)
 {
     if (c->profiling) (void)hipEventRecord(c->ev[i], s);
@@ -396,6 +406,7 @@ int gr80211_rx_batch(gr80211_ctx *c, const void *d_iq0, const void *d_iq1, uint6
                      int32_t *d_out_len, int32_t *d_n_pdu, gr80211_frame_info *d_info, void *stream)
 {
     if (!c) return GR80211_ERR_ARG;
+    if (int rc_busy = refuse_if_pending(c, "gr80211_rx_batch")) return rc_busy;
     if (n == 0) return GR80211_OK;
     if (!d_iq0 || !desc || n < 0 || !d_out || !d_out_len || !d_n_pdu || out_stride < 8)
         return fail(c, GR80211_ERR_ARG, "gr80211_rx_batch: bad argument");
@@ -440,10 +451,12 @@ int gr80211_rx_finish(gr80211_ctx *c, uint8_t *d_out, int out_stride, int32_t *d
     if (!c) return GR80211_ERR_ARG;
     if (!c->pending.active) return fail(c, GR80211_ERR_ARG, "gr80211_rx_finish: no batch has been submitted");
     const auto p = c->pending;
-    c->pending.active = false;
+    // a call that is refused for its arguments leaves the submitted batch in place: the caller may finish it again
+    if (p.n > 0 && (!d_out || !d_out_len || !d_n_pdu || out_stride < 8))
+        return fail(c, GR80211_ERR_ARG, "gr80211_rx_finish: bad argument");
+    if (p.n > 0) HIP_TRY(c, hipSetDevice(c->device));
+    c->pending.active = false;  // from here on the batch is spent, whatever the launches below return
     if (p.n == 0) return GR80211_OK;
-    if (!d_out || !d_out_len || !d_n_pdu || out_stride < 8) return fail(c, GR80211_ERR_ARG, "gr80211_rx_finish: bad argument");
-    HIP_TRY(c, hipSetDevice(c->device));
     int rc = finish_decode_stages(c, p.stream, p.n, true, p.iq0, p.iq1, p.arena_len, p.desc, nullptr, d_out, out_stride, d_out_len,
                                   d_n_pdu, nullptr, 0, true, nullptr, nullptr);
     if (rc) return rc;
@@ -456,6 +469,7 @@ int gr80211_detect(gr80211_ctx *c, const void *d_iq, uint64_t n_samples, gr80211
                    int *n_desc, void *stream)
 {
     if (!c) return GR80211_ERR_ARG;
+    if (int rc_busy = refuse_if_pending(c, "gr80211_detect")) return rc_busy;
     if (!n_desc) return fail(c, GR80211_ERR_ARG, "gr80211_detect: bad argument");
     *n_desc = 0;
     if (n_samples == 0) return GR80211_OK;
@@ -478,6 +492,7 @@ int gr80211_rx_capture(gr80211_ctx *c, const void *d_iq0, const void *d_iq1, uin
                        gr80211_frame_desc *d_desc_out, int *n_frames, void *stream)
 {
     if (!c) return GR80211_ERR_ARG;
+    if (int rc_busy = refuse_if_pending(c, "gr80211_rx_capture")) return rc_busy;
     if (!n_frames) return fail(c, GR80211_ERR_ARG, "gr80211_rx_capture: bad argument");
     *n_frames = 0;
     if (n_samples == 0) return GR80211_OK;
@@ -531,6 +546,7 @@ int gr80211_signal_batch(gr80211_ctx *c, const void *d_iq0, const void *d_iq1, u
                          const gr80211_frame_desc *desc, int n, unsigned flags, gr80211_frame_info *d_info, void *stream)
 {
     if (!c) return GR80211_ERR_ARG;
+    if (int rc_busy = refuse_if_pending(c, "gr80211_signal_batch")) return rc_busy;
     if (n == 0) return GR80211_OK;
     if (!d_iq0 || !desc || n < 0 || !d_info) return fail(c, GR80211_ERR_ARG, "gr80211_signal_batch: bad argument");
     if (n > (1 << 20)) return fail(c, GR80211_ERR_ARG, "gr80211_signal_batch: at most 1048576 frames per call");
@@ -549,6 +565,7 @@ int gr80211_signal_emit_batch(gr80211_ctx *c, const void *d_iq0, const void *d_i
                               void *d_out1, uint64_t out_len, gr80211_frame_info *d_info, void *d_chan, void *stream)
 {
     if (!c) return GR80211_ERR_ARG;
+    if (int rc_busy = refuse_if_pending(c, "gr80211_signal_emit_batch")) return rc_busy;
     if (n == 0) return GR80211_OK;
     if (!d_iq0 || !desc || n < 0 || !out_off || !d_out0 || (d_iq1 && !d_out1) || arena_len == 0)
         return fail(c, GR80211_ERR_ARG, "gr80211_signal_emit_batch: bad argument");
@@ -577,6 +594,7 @@ int gr80211_demod_tagged_batch(gr80211_ctx *c, const void *d_iq0, const void *d_
                                gr80211_frame_info *d_info, const float **d_llr, uint64_t *llr_floats, void *stream)
 {
     if (!c) return GR80211_ERR_ARG;
+    if (int rc_busy = refuse_if_pending(c, "gr80211_demod_tagged_batch")) return rc_busy;
     if (!d_iq0 || !desc || n < 0 || !d_llr || !d_chan || arena_len == 0)
         return fail(c, GR80211_ERR_ARG, "gr80211_demod_tagged_batch: bad argument");
     if (n > (1 << 20)) return fail(c, GR80211_ERR_ARG, "gr80211_demod_tagged_batch: at most 1048576 frames per call");
@@ -608,6 +626,7 @@ int gr80211_demod_batch(gr80211_ctx *c, const void *d_iq0, const void *d_iq1, ui
                         const float **d_llr, uint64_t *llr_floats, void *stream)
 {
     if (!c) return GR80211_ERR_ARG;
+    if (int rc_busy = refuse_if_pending(c, "gr80211_demod_batch")) return rc_busy;
     if (!d_iq0 || !desc || n < 0 || !d_llr) return fail(c, GR80211_ERR_ARG, "gr80211_demod_batch: bad argument");
     if (n > (1 << 20)) return fail(c, GR80211_ERR_ARG, "gr80211_demod_batch: at most 1048576 frames per call");
     *d_llr = nullptr;
@@ -631,6 +650,7 @@ int gr80211_decode_batch(gr80211_ctx *c, const float *d_llr, uint64_t llr_floats
                          uint8_t *d_bits, int bits_stride, void *stream)
 {
     if (!c) return GR80211_ERR_ARG;
+    if (int rc_busy = refuse_if_pending(c, "gr80211_decode_batch")) return rc_busy;
     if (n == 0) return GR80211_OK;
     if (!d_llr || !desc || n < 0 || !d_out || !d_out_len || !d_n_pdu || out_stride < 8)
         return fail(c, GR80211_ERR_ARG, "gr80211_decode_batch: bad argument");
@@ -671,6 +691,7 @@ int gr80211_tx_batch(gr80211_ctx *c, const uint8_t *d_psdu, uint64_t psdu_bytes,
                      unsigned flags, void *d_iq0, void *d_iq1, uint64_t arena_len, int32_t *d_n_samples, void *stream)
 {
     if (!c) return GR80211_ERR_ARG;
+    if (int rc_busy = refuse_if_pending(c, "gr80211_tx_batch")) return rc_busy;
     if (n == 0) return GR80211_OK;
     if (!d_psdu || !desc || n < 0 || !d_iq0) return fail(c, GR80211_ERR_ARG, "gr80211_tx_batch: bad argument");
     if (n > (1 << 20)) return fail(c, GR80211_ERR_ARG, "gr80211_tx_batch: at most 1048576 frames per call");
@@ -689,6 +710,7 @@ int gr80211_tx_mu_batch(gr80211_ctx *c, const uint8_t *d_psdu, uint64_t psdu_byt
                         int32_t *d_n_samples, void *stream)
 {
     if (!c) return GR80211_ERR_ARG;
+    if (int rc_busy = refuse_if_pending(c, "gr80211_tx_mu_batch")) return rc_busy;
     if (n == 0) return GR80211_OK;
     if (!d_psdu || !desc || n < 0 || !d_q || n_q < 1 || !d_iq0 || !d_iq1)
         return fail(c, GR80211_ERR_ARG, "gr80211_tx_mu_batch: bad argument");

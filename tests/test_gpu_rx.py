@@ -547,6 +547,32 @@ def test_submit_and_finish_on_two_contexts_from_one_thread(pkg, oracle):
                 ctxs[1].rx_submit(jobs[1][0], None, jobs[1][1], jobs[1][2])   # the batch before is not finished
             with pytest.raises(RuntimeError):
                 ctxs[1].rx_batch(jobs[1][0], None, jobs[1][1], jobs[1][2])    # nor may another batch call cut in
+        if rnd == 2:
+            # every other batch entry point is refused before it touches the workspaces the submitted batch lives
+            # in (frame records, descriptors): larger batches than the pending one, so that a call that got past the
+            # check would reallocate them
+            big = 4 * jobs[1][2] + 1000
+            llr = torch.zeros(big * 64, dtype=torch.float32, device="cuda")
+            dd = np.zeros(big, dtype=pkg.rx.DEC_DESC_DTYPE)
+            dd["llr_off"], dd["n_llr"], dd["trellis"], dd["len"] = np.arange(big) * 64, 64, 30, 1
+            sd = np.zeros(big, dtype=pkg.rx.SIG_DESC_DTYPE)
+            sd["n_avail"], sd["len"], sd["nsamp"] = 400, 20, 640
+            fdesc = pkg.RxContext.make_desc(np.zeros(big, np.uint64), np.full(big, 400, np.uint32))
+            intruders = [
+                lambda: ctxs[1].decode_batch(llr, dd, big),
+                lambda: ctxs[1].demod_tagged(jobs[1][0], None, sd, big, np.zeros((big, 64), np.complex64)),
+                lambda: ctxs[1].demod_batch(jobs[1][0], None, fdesc, big),
+                lambda: ctxs[1].signal_batch(jobs[1][0], None, fdesc, big),
+                lambda: ctxs[1].signal_emit(jobs[1][0], None, fdesc, big, np.arange(big, dtype=np.uint64) * 1000, big * 1000),
+                lambda: ctxs[1].rx_capture(jobs[1][0]),
+                lambda: ctxs[1].detect(jobs[1][0]),
+            ]
+            for call in intruders:
+                with pytest.raises(RuntimeError, match="waiting for gr80211_rx_finish"):
+                    call()
+            # a finish call with a bad argument is refused and leaves the batch where it is
+            with pytest.raises(RuntimeError, match="bad argument"):
+                ctxs[1]._check(ctxs[1].lib.gr80211_rx_finish(ctxs[1].h, None, 4104, None, None, None), "gr80211_rx_finish")
         for ctx, o in zip(ctxs, outs):
             ctx.rx_finish(o[0], o[1], o[2], o[3])
         for ctx in ctxs:
