@@ -70,6 +70,8 @@ def lib():
                                       u8, C.c_int, ip, ip]
         L.orc_decode_ex.argtypes = [fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                     u8, C.c_int, ip, u8]
+        L.orc_capture_points.argtypes = [fp, C.c_int]
+        L.orc_capture_points.restype = None
         L.orc_sig_viterbi.argtypes = [fp, u8, C.c_int]
         L.orc_viterbi_bits.argtypes = [fp, C.c_int, C.c_int, C.c_int, u8]
         L.orc_get_table.argtypes = [C.c_char_p, ip, C.c_int, ip]
@@ -147,11 +149,12 @@ def decode(llr, format, length, cr, mcs, ampdu, trellis, want_bits=False, strict
     return res
 
 
-def rx_frame(iq0, iq1, sync_idx, rad=0.0, want_llr=True, mu_pos=0, strict=False):
+def rx_frame(iq0, iq1, sync_idx, rad=0.0, want_llr=True, mu_pos=0, strict=False, want_points=False):
     """Run signal -> demod/demod2 -> decode on one frame.
 
     iq0/iq1: complex64 capture(s) of each antenna (iq1 None for the SISO demod block);
     sync_idx: index of the sync byte (L-LTF start + 16).
+    want_points: also return the equalised constellation points, [symbol, stream, nSD] complex64.
     """
     iq0 = np.ascontiguousarray(iq0, dtype=np.complex64)
     navail = len(iq0) - sync_idx
@@ -167,10 +170,21 @@ def rx_frame(iq0, iq1, sync_idx, rad=0.0, want_llr=True, mu_pos=0, strict=False)
     out = np.zeros(8192, dtype=np.uint8)
     olen = C.c_int(0)
     npdu = C.c_int(0)
-    st = lib().orc_rx_frame_ex(p0, p1, navail, np.float32(rad), int(mu_pos), 1 if strict else 0, C.byref(f), _fp(llr),
-                               cap, _u8(out), len(out), C.byref(olen), C.byref(npdu))
+    pts = None
+    if want_points:
+        pts = np.zeros(cap // 2, dtype=np.complex64)
+        lib().orc_capture_points(_fp(pts.view(np.float32)), len(pts))
+    try:
+        st = lib().orc_rx_frame_ex(p0, p1, navail, np.float32(rad), int(mu_pos), 1 if strict else 0, C.byref(f), _fp(llr),
+                                   cap, _u8(out), len(out), C.byref(olen), C.byref(npdu))
+        npts = lib().orc_captured_points() if want_points else 0
+    finally:
+        if want_points:
+            lib().orc_capture_points(None, 0)
     blob = bytes(out[: olen.value])
     res = dict(status=st, frame=f, n_pdu=npdu.value, blob=blob, pdus=split_pdus(blob))
+    if want_points and st == 0:
+        res["points"] = pts[:npts].reshape(f.m.nSym, f.m.nSS, f.m.nSD).copy()
     if want_llr and st == 0:
         res["llr"] = llr[: f.total].copy()
     return res

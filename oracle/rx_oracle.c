@@ -822,6 +822,25 @@ static void vht_sigb(const src_t *s, int off, const orc_mod_t *m, int two_ant, c
     if (two) f->sssnr1 = (float)(log10(52.0 / n1) * 10.0);
 }
 
+/* Test hook: the equalised constellation points of every data symbol as the demodulator hands them to
+ * procSymQamToLlr (lib/demod_impl.cc:293-299, lib/demod2_impl.cc:283-296), i.e. before the constellation scaling:
+ * [symbol][stream][nSD] complex, re/im interleaved, in the tone order of the reference's arrays. */
+static __thread float *g_pts = NULL;
+static __thread int g_pts_cap = 0, g_pts_n = 0;
+void orc_capture_points(float *buf_ri, int cap_complex)
+{
+    g_pts = buf_ri;
+    g_pts_cap = buf_ri ? cap_complex : 0;
+    g_pts_n = 0;
+}
+int orc_captured_points(void) { return g_pts_n; }
+static void keep_points(const cf *q, int n)
+{
+    if (!g_pts || g_pts_n + n > g_pts_cap) return;
+    memcpy(g_pts + 2 * g_pts_n, q, sizeof(cf) * (size_t)n);
+    g_pts_n += n;
+}
+
 int orc_demod(const float *in0_ri, const float *in1_ri, int navail, float rad, orc_frame_t *f,
               float *llr, int llr_cap)
 {
@@ -943,14 +962,18 @@ int orc_demod(const float *in0_ri, const float *in1_ri, int navail, float rad, o
             int off = pos + n * m->nSymSamp;
             if (m->format == ORC_F_L) {
                 legacy_update(&s, off, c, q0);
+                keep_points(q0, m->nSD);
                 qam_to_llr(q0, li0, m);
                 deint_l(li0, o, m);
             } else if (m->nSS == 1) {
                 nl1_update(&s, off, c, q0);
+                keep_points(q0, m->nSD);
                 qam_to_llr(q0, li0, m);
                 deint_nl(li0, o, m, 0);
             } else {
                 nl2_update(&s, off, c, m->format == ORC_F_VHT, q0, q1);
+                keep_points(q0, m->nSD);
+                keep_points(q1, m->nSD);
                 qam_to_llr(q0, li0, m);
                 qam_to_llr(q1, li1, m);
                 deint_nl(li0, sp0, m, 0);

@@ -99,6 +99,12 @@ int orc_rx_frame_ex(const float *in0_ri, const float *in1_ri, int navail, float 
                     orc_frame_t *f, float *llr, int llr_cap,
                     uint8_t *out, int out_cap, int *out_len, int *n_pdu);
 
+/* Test hook: until it is called again with NULL, orc_demod (and the whole-chain calls) of this thread copy the
+ * equalised constellation points of every data symbol to buf_ri ([symbol][stream][nSD] complex); orc_captured_points
+ * = complex values written by the calls since. */
+void orc_capture_points(float *buf_ri, int cap_complex);
+int orc_captured_points(void);
+
 /* Small pieces exported for table / known-answer tests. */
 void orc_sig_viterbi(const float *llr, uint8_t *bits, int trellis);      /* cloud80211phy.cc:2001-2088 */
 int orc_viterbi_bits(const float *llr, int nllr, int cr, int trellis, uint8_t *scram_bits); /* decode_impl.cc:205-302 */

@@ -43,7 +43,10 @@ def mpdu_of(n, seed):
     return body + struct.pack("<L", zlib.crc32(body) & 0xFFFFFFFF)
 
 
-def gen(fmt, mcs, nsts, mpdu, cfo_hz=0.0):
+def gen(fmt, mcs, nsts, mpdu, cfo_hz=0.0, keep=None):
+    """keep: a dict that receives what the generator holds after building the frame -- the coded (punctured) bits of
+    its one encoder, the interleaved bits and the constellation points of every spatial stream
+    (phy80211.esCodedBits / ssIntedBits / ssSymbols, tools/phy80211.py:51-54,716-805) -- as arrays."""
     phy = phy80211.phy80211(ifDebug=False)
     with contextlib.redirect_stdout(io.StringIO()):
         if fmt == "L":
@@ -55,6 +58,12 @@ def gen(fmt, mcs, nsts, mpdu, cfo_hz=0.0):
             phy.genFromAmpdu(ampdu, p8h.modulation(p8h.F.VHT, mcs, p8h.BW.BW20, nsts, False),
                              vhtPartialAid=0, vhtGroupId=0)
         ss = phy.genFinalSig(multiplier=12.0 * np.sqrt(nsts), cfoHz=cfo_hz, num=1, gap=True, gapLen=GAP)
+    if keep is not None:
+        assert len(phy.esCodedBits) == 1
+        keep["coded"] = np.array(phy.esCodedBits[0], dtype=np.uint8)
+        keep["inted"] = np.array(phy.ssIntedBits, dtype=np.uint8)
+        keep["symbols"] = np.array(phy.ssSymbols, dtype=np.complex128)
+        keep["nsym"], keep["nsd"], keep["nbpscs"] = int(phy.m.nSym), int(phy.m.nSD), int(phy.m.nBPSCS)
     return np.array(ss, dtype=np.complex128)
 
 
@@ -95,6 +104,24 @@ def make_frames():
             mpdu=np.frombuffer(mpdu, dtype=np.uint8),
             fmt=np.int32({"L": 0, "HT": 1, "VHT": 2}[fmt]), mcs=np.int32(mcs), nss=np.int32(nsts))
         print("frame", name, rx.shape)
+
+
+def make_soft():
+    """Companions of the frame_*.npz fixtures (same frames, same seeds): the generator's own coded bits, interleaved
+    bits and constellation points, which pin the receiver's equalised points and soft bits -- values, order and
+    scale -- to data the reference holds.  Bits are stored packed (np.packbits, big-endian bit order)."""
+    for idx, (name, fmt, mcs, nsts, nbytes, cfo) in enumerate(CASES):
+        keep = {}
+        tx = gen(fmt, mcs, nsts, mpdu_of(nbytes, 1000 + idx), cfo, keep=keep)
+        old = np.load(os.path.join(HERE, "frame_%s.npz" % name))
+        rx = (H22 @ tx) if nsts == 2 else tx
+        assert np.array_equal(old["iq"], rx.astype(np.complex64)), name   # the very frame the IQ fixture holds
+        np.savez_compressed(
+            os.path.join(HERE, "soft_%s.npz" % name),
+            coded=np.packbits(keep["coded"]), n_coded=np.int32(len(keep["coded"])),
+            inted=np.packbits(keep["inted"], axis=1), symbols=keep["symbols"].astype(np.complex64),
+            nsym=np.int32(keep["nsym"]), nsd=np.int32(keep["nsd"]), nbpscs=np.int32(keep["nbpscs"]))
+        print("soft", name, keep["symbols"].shape, len(keep["coded"]))
 
 
 def make_ndp():
@@ -208,6 +235,7 @@ if __name__ == "__main__":
     make_txbits()
     make_viterbi()
     make_frames()
+    make_soft()
     make_ndp()
     make_mu()
     make_ampdu()

@@ -91,6 +91,31 @@ def test_golden_frames_2x2(pkg, rxctx, oracle):
         assert [p["mpdu"] for p in ref["pdus"]] == [f["mpdu"]], f["name"]
 
 
+def test_soft_bits_against_reference_generator(pkg, rxctx):
+    """The GPU demodulator's soft bits on the noise-free golden frames against the stream worked out from the
+    constellation points the reference's own transmitter held for them (tests/golden/soft_*.npz, max-log formula and
+    interleaver written out in tests/util.py): values to 1e-4 relative + the floor, signs = the generator's coded
+    bits.  No oracle in the loop."""
+    import torch
+    from util import expected_llr_from_generator, golden_soft
+    for two in (False, True):
+        gf = [f for f in golden_frames() if (f["nss"] == 2) == two]
+        frames = [([f["iq"][a] for a in range(f["iq"].shape[0])], f["sync_idx"]) for f in gf]
+        iq0, iq1, sync, navail = build_arena(frames)
+        desc = rxctx.make_desc(sync, navail, rad=np.array([f["rad"] for f in gf], np.float32))
+        d0 = torch.from_numpy(iq0).cuda()
+        d1 = torch.from_numpy(iq1).cuda() if two else None
+        info, llr = rxctx.demod_batch(d0, d1, desc, len(gf))
+        for i, f in enumerate(gf):
+            soft = golden_soft(f["name"])
+            want = expected_llr_from_generator(soft, legacy=f["fmt"] == 0)
+            assert int(info["status"][i]) == 0 and int(info["total"][i]) == len(want), f["name"]
+            got = llr[int(info["llr_off"][i]): int(info["llr_off"][i]) + len(want)]
+            assert np.array_equal(got > 0, soft["coded"] == 1), f["name"]
+            err = np.abs(got - want)
+            assert np.all(err <= LLR_RTOL * np.abs(want) + LLR_ATOL), (f["name"], float(err.max()))
+
+
 def make_noisy(tx, rng, fmt, mcs, nss, nbytes, snr_db, cfo_hz=0.0):
     mpdu = tx.make_mpdu(nbytes, rng)
     sig, m = tx.gen_frame(fmt, mcs, nss, mpdu)

@@ -20,6 +20,76 @@ def golden_frames():
     return out
 
 
+def golden_soft(name):
+    """What the reference's Python generator held after building golden frame `name` (tests/golden/make_golden.py
+    make_soft): coded bits of the one encoder after puncturing [nSym * nCBPS], interleaved bits [nSS, nSym * nCBPSS],
+    constellation points [nSym, nSS, nSD] (unit average power, tools/phy80211.py:796-805)."""
+    z = np.load(os.path.join(GOLDEN, "soft_%s.npz" % name))
+    nsym, nsd, nb = int(z["nsym"]), int(z["nsd"]), int(z["nbpscs"])
+    nss = z["symbols"].shape[0]
+    return dict(coded=np.unpackbits(z["coded"])[: int(z["n_coded"])],
+                inted=np.unpackbits(z["inted"], axis=1)[:, : nsym * nsd * nb],
+                points=z["symbols"].reshape(nss, nsym, nsd).transpose(1, 0, 2), nsym=nsym, nsd=nsd, nbpscs=nb, nss=nss)
+
+
+QAM_SCALE = {1: 1.0, 2: 1.4142135623730951, 4: 3.1622776601683795, 6: 6.48074069840786, 8: 13.038404810405298}
+
+
+def maxlog_llr(points, nbpscs):
+    """Max-log soft bits of constellation points as the reference's procSymQamToLlr forms them
+    (lib/cloud80211phy.cc:2090-2148), in float32: per point the I-axis bits, then the Q-axis bits; per axis
+    x, E - |x|, E/2 - |E - |x||, ... with E = 2, 4, 8 for 2, 3, 4 bits.  Returns [..., nbpscs]."""
+    q = np.asarray(points, np.complex64)
+    if nbpscs == 1:
+        return q.real.astype(np.float32)[..., None]
+    q = q * np.float32(QAM_SCALE[nbpscs])
+    nax = nbpscs // 2
+    out = np.zeros(q.shape + (nbpscs,), np.float32)
+    for a, v in enumerate((q.real.astype(np.float32), q.imag.astype(np.float32))):
+        cur = v
+        out[..., a * nax] = cur
+        edge = np.float32(2 ** (nax - 1))
+        for b in range(1, nax):
+            cur = edge - np.abs(cur)
+            out[..., a * nax + b] = cur
+            edge = edge / np.float32(2)
+    return out
+
+
+def interleaver_position(k, ncbpss, nbpscs, legacy, iss=0):
+    """Place of stream bit k of one OFDM symbol after the interleaver, from the standard's formulas (IEEE 802.11-2016
+    17.3.5.7 for the 16-column legacy interleaver, 19.3.11.8.3 for HT/VHT at 20 MHz: 13 columns, 4 N_BPSCS rows,
+    frequency rotation 11 N_BPSCS places per stream index step of the second stream)."""
+    s = max(nbpscs // 2, 1)
+    if legacy:
+        i = (ncbpss // 16) * (k % 16) + k // 16
+        return s * (i // s) + (i + ncbpss - (16 * i) // ncbpss) % s
+    i = 4 * nbpscs * (k % 13) + k // 13
+    j = s * (i // s) + (i + ncbpss - (13 * i) // ncbpss) % s
+    if iss:
+        j = (j - ((iss * 2) % 3 + 3 * (iss // 3)) * 11 * nbpscs) % ncbpss
+    return j
+
+
+def expected_llr_from_generator(soft, legacy):
+    """The soft-bit stream `demod` hands to `decode` for a noise-free frame, worked out from the generator's
+    constellation points alone: max-log soft bits per tone, taken out of the interleaver (and, for two streams, out
+    of the stream parser: blocks of max(N_BPSCS / 2, 1) coded bits go to the streams in turn) with the standard's
+    formulas.  Element c of symbol n is the soft bit of coded bit n * nCBPS + c."""
+    nsym, nsd, nb, nss = soft["nsym"], soft["nsd"], soft["nbpscs"], soft["nss"]
+    ncbpss = nsd * nb
+    per_tone = maxlog_llr(soft["points"], nb).reshape(nsym, nss, ncbpss)   # interleaved order within a stream
+    out = np.zeros((nsym, nss * ncbpss), np.float32)
+    s = max(nb // 2, 1)
+    k = np.arange(ncbpss)
+    for iss in range(nss):
+        r = np.array([interleaver_position(int(x), ncbpss, nb, legacy, iss) for x in k])
+        stream = per_tone[:, iss, :][:, r]                                  # stream bit k sits at interleaved place r(k)
+        c = iss * s + nss * s * (k // s) + k % s if nss > 1 else k          # coded bit the stream's k-th bit is
+        out[:, c] = stream
+    return out.reshape(-1)
+
+
 def golden_ndp():
     z = np.load(os.path.join(GOLDEN, "ndp_vht_2sts.npz"))
     return dict(iq=z["iq"], sync_idx=int(z["sync_idx"]), rad=float(z["rad"]))
