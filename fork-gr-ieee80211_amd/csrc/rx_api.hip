@@ -22,7 +22,16 @@ namespace {
 struct Buf {
     void *p = nullptr;
     size_t cap = 0;
+    bool fixed = false;  // a piece of the fixed scratch array: never grown, never freed
 };
+
+// ---- work memory of gr80211_decode_batch_noalloc: one array per GPU, part of the code object, so the entry point
+// never allocates.  In host code the array's name is only a handle for hipGetSymbolAddress; g_scratch[device] is
+// the address of that device's copy and is what kernels, copies and memsets take.
+constexpr int NA_MAX_FRAMES = 1024;
+constexpr size_t NA_SCRATCH_BYTES = (size_t)48 << 20;
+static __device__ __align__(256) unsigned char scratch[NA_SCRATCH_BYTES];
+void *g_scratch[64] = {};
 
 }  // namespace
 
@@ -47,6 +56,7 @@ struct gr80211_ctx {
     } pending = {};
     uint32_t *det_totals_h = nullptr;  // pinned
     SchedTotals *totals_h = nullptr;  // pinned
+    gr80211_dec_desc *na_desc_h = nullptr;  // pinned: descriptors of gr80211_decode_batch_noalloc on their way to the GPU
     int ampdu_strict = 0;  // de-aggregate A-MPDUs by the standard's rules instead of the reference's
     uint32_t mu_pos = 0;  // MU group position written into the descriptors frame detection makes
     bool profiling = false;
@@ -90,6 +100,7 @@ int fail(gr80211_ctx *c, int code, const char *what, hipError_t e = hipSuccess)
 int ensure(gr80211_ctx *c, Buf &b, size_t bytes)
 {
     if (bytes <= b.cap) return GR80211_OK;
+    if (b.fixed) return fail(c, GR80211_ERR_NOMEM, "the batch needs more work memory than the fixed scratch array holds");
     // grow with headroom so steady-state batches of similar size never reallocate
     size_t want = bytes + bytes / 8 + 4096;
     if (b.p) {
@@ -109,7 +120,7 @@ int ensure(gr80211_ctx *c, Buf &b, size_t bytes)
 
 void release(Buf &b)
 {
-    if (b.p) (void)hipFree(b.p);
+    if (b.p && !b.fixed) (void)hipFree(b.p);
     b.p = nullptr;
     b.cap = 0;
 }
@@ -345,10 +356,14 @@ int gr80211_create(gr80211_ctx **out, int device)
     {
         std::lock_guard<std::mutex> lk(g_upload_mutex);
         if (!g_uploaded[device]) {
-            if (upload_tables(tables()) != 0 || upload_tx_tables(tables()) != 0) {
+            // this device's copy of the scratch array: the address is taken once, with the device current
+            void *sp = nullptr;
+            if (upload_tables(tables()) != 0 || upload_tx_tables(tables()) != 0 ||
+                hipGetSymbolAddress(&sp, HIP_SYMBOL(scratch)) != hipSuccess || !sp) {
                 delete c;
                 return GR80211_ERR_HIP;
             }
+            g_scratch[device] = sp;
             g_uploaded[device] = true;
         }
     }
@@ -361,7 +376,8 @@ int gr80211_create(gr80211_ctx **out, int device)
         delete c;
         return GR80211_ERR_NOMEM;
     }
-    if (hipHostMalloc((void **)&c->det_totals_h, 4 * sizeof(uint32_t)) != hipSuccess) {
+    if (hipHostMalloc((void **)&c->det_totals_h, 4 * sizeof(uint32_t)) != hipSuccess ||
+        hipHostMalloc((void **)&c->na_desc_h, NA_MAX_FRAMES * sizeof(gr80211_dec_desc)) != hipSuccess) {
         gr80211_destroy(c);
         return GR80211_ERR_NOMEM;
     }
@@ -386,6 +402,7 @@ void gr80211_destroy(gr80211_ctx *c)
         release(*b);
     if (c->totals_h) (void)hipHostFree(c->totals_h);
     if (c->det_totals_h) (void)hipHostFree(c->det_totals_h);
+    if (c->na_desc_h) (void)hipHostFree(c->na_desc_h);
     for (auto &e : c->ev)
         if (e) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -677,6 +694,140 @@ int gr80211_decode_batch(gr80211_ctx *c, const float *d_llr, uint64_t llr_floats
     mark(c, 1, s);
     rc = run_decode_stages(c, s, n, false, nullptr, nullptr, 0, nullptr, d_llr, d_out, out_stride, d_out_len, d_n_pdu,
                            d_bits, bits_stride, true, nullptr, nullptr);
+    if (rc) return rc;
+    return finish_timing(c, s);
+}
+
+int gr80211_decode_batch_noalloc(gr80211_ctx *c, const float *d_llr, uint64_t llr_floats, const gr80211_dec_desc *h_desc, int n,
+                                 uint8_t *d_out, int out_stride, int32_t *d_out_len, int32_t *d_n_pdu, uint8_t *d_bits,
+                                 int bits_stride, void *stream)
+{
+    if (!c) return GR80211_ERR_ARG;
+    if (int rc_busy = refuse_if_pending(c, "gr80211_decode_batch_noalloc")) return rc_busy;
+    if (n == 0) return GR80211_OK;
+    if (!d_llr || !h_desc || n < 0 || !d_out || !d_out_len || !d_n_pdu || out_stride < 8)
+        return fail(c, GR80211_ERR_ARG, "gr80211_decode_batch_noalloc: bad argument");
+    if (d_bits && (bits_stride < 4 || (bits_stride & 3)))
+        return fail(c, GR80211_ERR_ARG, "gr80211_decode_batch_noalloc: bits_stride must be a multiple of 4");
+    if (n > NA_MAX_FRAMES) return fail(c, GR80211_ERR_ARG, "gr80211_decode_batch_noalloc: at most 1024 frames per call");
+    for (int i = 0; i < n; i++)
+        if (h_desc[i].llr_off < 0 || h_desc[i].n_llr < 0 || (uint64_t)h_desc[i].llr_off + (uint64_t)h_desc[i].n_llr > llr_floats)
+            return fail(c, GR80211_ERR_ARG, "gr80211_decode_batch_noalloc: descriptor outside the LLR arena");
+
+    // The scratch array in pieces (256-byte aligned), sized for NA_MAX_FRAMES frames; survivor words take what is left.
+    struct Carver {
+        size_t at, size;
+        char *base;
+        Buf take(size_t bytes)
+        {
+            bytes = (bytes + 255) & ~(size_t)255;
+            Buf b;
+            b.fixed = true;
+            if (at + bytes <= size) {
+                b.p = base ? base + at : nullptr;
+                b.cap = bytes;
+                at += bytes;
+            }
+            return b;
+        }
+    };
+    const int slot_cap = NA_MAX_FRAMES + 4 * 64 + 64, group_cap = slot_cap / 64 + 1;
+    const size_t piece[7] = {NA_MAX_FRAMES * sizeof(gr80211_dec_desc), NA_MAX_FRAMES * sizeof(gr80211_frame_info),
+                             (size_t)slot_cap * sizeof(int32_t), (size_t)group_cap * sizeof(GroupInfo), sizeof(SchedTotals),
+                             (size_t)SCHED_WS_WORDS * sizeof(uint32_t),
+                             (size_t)(NA_MAX_FRAMES / 256 + 2) * sizeof(unsigned long long)};
+    size_t fixed_part = 0;
+    for (size_t b : piece) fixed_part += (b + 255) & ~(size_t)255;
+    const size_t bits_bytes = (size_t)1 << 20;
+    const size_t dec_bytes = NA_SCRATCH_BYTES - fixed_part - bits_bytes;
+
+    // What the scheduler kernels will ask for, worked out here from the descriptors so that a batch beyond the array
+    // is refused before anything is launched: the frames the decoder admits (k_desc_to_info, k_sched_hist), counted
+    // per code rate and 64-step length bin, cut into groups of 64 in that order; a group runs as many steps as its
+    // longest frame, which is at most the longest frame of the last bin it takes frames from.
+    {
+        static thread_local uint16_t cnt[4][SCHED_NB];
+        static thread_local int32_t longest[4][SCHED_NB];
+        memset(cnt, 0, sizeof(cnt));
+        memset(longest, 0, sizeof(longest));
+        for (int i = 0; i < n; i++) {
+            const gr80211_dec_desc &d = h_desc[i];
+            if (d.cr < 0 || d.cr > 3 || d.trellis <= 0 || d.trellis > GR80211_MAX_TRELLIS || d.len > GR80211_MAX_PSDU) continue;
+            const int P = d.cr == CR_12 ? 1 : d.cr == CR_23 ? 2 : d.cr == CR_34 ? 3 : 5;
+            const int q = d.trellis / P, rem = d.trellis % P;
+            if (d.n_llr < q * (P + 1) + (rem ? rem + 1 : 0)) continue;
+            cnt[d.cr][d.trellis / 64]++;
+            if (d.trellis > longest[d.cr][d.trellis / 64]) longest[d.cr][d.trellis / 64] = d.trellis;
+        }
+        uint64_t dec_words = 0, bits_words = 0;
+        for (int cr = 0; cr < 4; cr++) {
+            const int cs = chunk_steps(cr);
+            int in_group = 0, top = 0;
+            auto close = [&] {
+                const int steps = (top + cs - 1) / cs * cs;
+                dec_words += (uint64_t)steps * 128u;
+                bits_words += (uint64_t)((steps + 31) / 32) * 64u;
+                in_group = 0;
+                top = 0;
+            };
+            for (int b = 0; b < SCHED_NB; b++) {
+                int left = cnt[cr][b];
+                while (left > 0) {
+                    const int take = left < 64 - in_group ? left : 64 - in_group;
+                    in_group += take;
+                    left -= take;
+                    top = longest[cr][b];
+                    if (in_group == 64) close();
+                }
+            }
+            if (in_group) close();
+        }
+        if ((dec_words + 128) * sizeof(uint32_t) > dec_bytes || (bits_words + 64) * sizeof(uint32_t) > bits_bytes) {
+            char msg[200];
+            snprintf(msg, sizeof(msg),
+                     "gr80211_decode_batch_noalloc: the batch needs %llu bytes of survivor words, the scratch array holds %llu",
+                     (unsigned long long)((dec_words + 128) * sizeof(uint32_t)), (unsigned long long)dec_bytes);
+            return fail(c, GR80211_ERR_ARG, msg);
+        }
+    }
+
+    HIP_TRY(c, hipSetDevice(c->device));
+    char *base = static_cast<char *>(g_scratch[c->device]);
+    if (!base) return fail(c, GR80211_ERR_HIP, "gr80211_decode_batch_noalloc: no scratch array on this device");
+    hipStream_t s = pick(c, stream);
+    Carver cv = {0, NA_SCRATCH_BYTES, base};
+    // the context's own work buffers step aside for the duration of the call
+    struct Swap {
+        gr80211_ctx *c;
+        Buf ddesc, info, slot_frame, groups, totals_d, sched_ws, blk_llr, dec, bitsw;
+        explicit Swap(gr80211_ctx *cc)
+            : c(cc), ddesc(cc->ddesc), info(cc->info), slot_frame(cc->slot_frame), groups(cc->groups), totals_d(cc->totals_d),
+              sched_ws(cc->sched_ws), blk_llr(cc->blk_llr), dec(cc->dec), bitsw(cc->bitsw) {}
+        ~Swap()
+        {
+            c->ddesc = ddesc; c->info = info; c->slot_frame = slot_frame; c->groups = groups; c->totals_d = totals_d;
+            c->sched_ws = sched_ws; c->blk_llr = blk_llr; c->dec = dec; c->bitsw = bitsw;
+        }
+    } keep(c);
+    c->ddesc = cv.take(piece[0]);
+    c->info = cv.take(piece[1]);
+    c->slot_frame = cv.take(piece[2]);
+    c->groups = cv.take(piece[3]);
+    c->totals_d = cv.take(piece[4]);
+    c->sched_ws = cv.take(piece[5]);
+    c->blk_llr = cv.take(piece[6]);
+    c->bitsw = cv.take(bits_bytes);
+    c->dec = cv.take(dec_bytes);
+
+    // the descriptors travel through page-locked memory the context has held since it was created; the copy has
+    // left that memory when the call returns (the stream is synchronised below, for the scheduler's totals)
+    memcpy(c->na_desc_h, h_desc, (size_t)n * sizeof(gr80211_dec_desc));
+    HIP_TRY(c, hipMemcpyAsync(c->ddesc.p, c->na_desc_h, (size_t)n * sizeof(gr80211_dec_desc), hipMemcpyHostToDevice, s));
+    mark(c, 0, s);
+    launch_desc_to_info((const gr80211_dec_desc *)c->ddesc.p, n, llr_floats, (gr80211_frame_info *)c->info.p, s);
+    mark(c, 1, s);
+    int rc = run_decode_stages(c, s, n, false, nullptr, nullptr, 0, nullptr, d_llr, d_out, out_stride, d_out_len, d_n_pdu, d_bits,
+                               bits_stride, true, nullptr, nullptr);
     if (rc) return rc;
     return finish_timing(c, s);
 }

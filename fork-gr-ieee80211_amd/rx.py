@@ -71,7 +71,7 @@ EXPORTS = [
     "gr80211_copy_h2d", "gr80211_copy_d2h", "gr80211_set_profiling", "gr80211_last_timing",
     "gr80211_version", "gr80211_table_checksum", "gr80211_tx_samples", "gr80211_tx_batch", "gr80211_set_mu_pos", "gr80211_set_ampdu_strict", "gr80211_tx_mu_batch",
     "gr80211_host_alloc", "gr80211_host_free", "gr80211_copy_d2d", "gr80211_signal_emit_batch", "gr80211_demod_tagged_batch",
-    "gr80211_rx_submit", "gr80211_rx_finish",
+    "gr80211_rx_submit", "gr80211_rx_finish", "gr80211_decode_batch_noalloc",
 ]
 
 _lib = None
@@ -105,6 +105,7 @@ def load_library():
                                       C.POINTER(C.c_uint64), vp]
     L.gr80211_decode_batch.argtypes = [vp, vp, C.c_uint64, vp, C.c_int, C.c_uint, vp, C.c_int, vp, vp, vp,
                                        C.c_int, vp]
+    L.gr80211_decode_batch_noalloc.argtypes = [vp, vp, C.c_uint64, vp, C.c_int, vp, C.c_int, vp, vp, vp, C.c_int, vp]
     L.gr80211_dev_alloc.argtypes = [vp, C.c_size_t]
     L.gr80211_dev_alloc.restype = vp
     L.gr80211_host_alloc.argtypes = [vp, C.c_size_t]
@@ -404,6 +405,18 @@ class RxContext:
             bits_stride if bits is not None else 0, self._stream())
         self._check(rc, "gr80211_decode_batch")
         return dict(out=out, out_len=out_len, n_pdu=n_pdu, bits=bits, _keep=keep)
+
+    def decode_batch_noalloc(self, llr, desc, n_frames, out, out_len, n_pdu, bits=None):
+        """gr80211_decode_batch_noalloc: LLRs -> PDUs inside the library's fixed scratch array.  desc: DEC_DESC_DTYPE
+        ndarray on the host; out [n, stride] u8, out_len [n], n_pdu [n] i32 and bits [n, stride] u8 (optional) are CUDA
+        tensors of the caller: nothing is allocated here either."""
+        desc = np.ascontiguousarray(desc)
+        rc = self.lib.gr80211_decode_batch_noalloc(
+            self.h, C.c_void_p(llr.data_ptr()), llr.numel(), C.c_void_p(desc.ctypes.data), n_frames,
+            C.c_void_p(out.data_ptr()), out.shape[1], C.c_void_p(out_len.data_ptr()), C.c_void_p(n_pdu.data_ptr()),
+            C.c_void_p(bits.data_ptr()) if bits is not None else None, bits.shape[1] if bits is not None else 0,
+            self._stream())
+        self._check(rc, "gr80211_decode_batch_noalloc")
 
     # -- transmitter ---------------------------------------------------------------------
     @staticmethod

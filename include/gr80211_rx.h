@@ -267,6 +267,25 @@ int gr80211_decode_batch(gr80211_ctx *ctx, const float *d_llr, uint64_t llr_floa
                          uint8_t *d_bits, int bits_stride, void *stream);
 
 /*
+ * gr80211_decode_batch for callers that cannot allocate device memory once they run: serving loops and test
+ * harnesses that forbid hipMalloc / hipFree after start-up.  No counterpart in the reference.  Same inputs, outputs and
+ * results as gr80211_decode_batch, with these differences: the descriptors are a HOST array (the limits below are
+ * checked on them before anything is launched); every work buffer (frame records, decoder lanes, survivor words,
+ * decoded bits) lies in one 48-MiB array that is part of the library's code object, one copy per GPU, held until the
+ * process ends; the call allocates and frees nothing, on the device or through any library.  Limits: at most 1024
+ * frames per call, and the survivor words of the batch -- 512 bytes per trellis step of every group of up to 64
+ * frames of one code rate, a group running as many steps as its longest frame -- must fit into the array's 46.8 MiB
+ * left for them (e.g. 448 frames of 1500 bytes at one rate, or 1024 frames of up to 700 bytes); a batch beyond
+ * either limit is refused with GR80211_ERR_ARG and gr80211_last_error says what it needed.  The array is shared by
+ * every context and stream of the process on that GPU and keeps the last call's contents: calls that overlap on one
+ * GPU race, so a caller runs them one after the other (the next call may start once the stream of the one before has
+ * been synchronised).  Like gr80211_decode_batch it waits once, inside the call, for the scheduler's totals.
+ */
+int gr80211_decode_batch_noalloc(gr80211_ctx *ctx, const float *d_llr, uint64_t llr_floats,
+                                 const gr80211_dec_desc *h_desc, int n_frames, uint8_t *d_out, int out_stride,
+                                 int32_t *d_out_len, int32_t *d_n_pdu, uint8_t *d_bits, int bits_stride, void *stream);
+
+/*
  * Synthetic transmitter: PSDU bytes -> 20-MHz baseband frames, the waveform of the reference's Python generator
  * (tools/phy80211.py genFromMpdu 80-117, genFromAmpdu 119-181, genFinalSig 1077-1094; the C++ blocks
  * encode / modulation / pad of lib/ implement the same standard clauses for the GNU Radio flowgraph).
