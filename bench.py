@@ -82,10 +82,10 @@ def build_corpus(torch, tx, wl, n_frames, n_unique, seed, dev):
     return arenas, sync, navail, exp, idx, L
 
 
-def build_corpus_gpu(torch, ctx, tx, wl, n_frames, seed, dev):
-    """Same corpus shape with a different random payload in every frame: the frames are generated by the GPU
-    transmitter (gr80211_tx_batch), mixed through the 2x2 channel if they have two streams, and noise is added.
-    Returns the tuple of build_corpus plus the transmitter's rate."""
+def payloads_uniform(wl, n_frames, seed):
+    """The MPDUs of corpus `seed` (one per frame, random bodies with their FCS) and the PDU blob each one comes back
+    as: [format][len lo][len hi][MPDU][mcs].  A function of (workload, frames, seed) alone, so that rank 0 can
+    rebuild what every other rank should have decoded."""
     import zlib
     fmt, mcs, nss, nbytes, snr_db, _ = WORKLOADS[wl]
     rng = np.random.default_rng(80211 + seed)
@@ -94,6 +94,17 @@ def build_corpus_gpu(torch, ctx, tx, wl, n_frames, seed, dev):
     mpdu[:, :nbytes - 4] = body
     fcs = np.fromiter((zlib.crc32(row) for row in body), dtype=np.uint32, count=n_frames)
     mpdu[:, nbytes - 4:] = fcs.astype("<u4").view(np.uint8).reshape(n_frames, 4)
+    blob = np.empty((n_frames, nbytes + 4), dtype=np.uint8)
+    blob[:, 0], blob[:, 1], blob[:, 2], blob[:, 3:3 + nbytes], blob[:, 3 + nbytes] = fmt, nbytes % 256, nbytes // 256, mpdu, mcs
+    return mpdu, blob
+
+
+def build_corpus_gpu(torch, ctx, tx, wl, n_frames, seed, dev):
+    """Same corpus shape with a different random payload in every frame: the frames are generated by the GPU
+    transmitter (gr80211_tx_batch), mixed through the 2x2 channel if they have two streams, and noise is added.
+    Returns the tuple of build_corpus plus the transmitter's rate."""
+    fmt, mcs, nss, nbytes, snr_db, _ = WORKLOADS[wl]
+    mpdu, blob = payloads_uniform(wl, n_frames, seed)
     if fmt == 2:
         # one-subframe A-MPDU: the delimiter and the padding are the same for every MPDU of this length
         shell = np.frombuffer(tx.ampdu_vht([bytes(nbytes)]), dtype=np.uint8)
@@ -132,8 +143,6 @@ def build_corpus_gpu(torch, ctx, tx, wl, n_frames, seed, dev):
             v[s:e] += torch.randn((e - s, 2), generator=gen, device=dev, dtype=torch.float32) * sigma
     sync = (np.arange(n_frames, dtype=np.uint64) * L + 176)
     navail = np.full(n_frames, L - 176, dtype=np.uint32)
-    blob = np.empty((n_frames, nbytes + 4), dtype=np.uint8)
-    blob[:, 0], blob[:, 1], blob[:, 2], blob[:, 3:3 + nbytes], blob[:, 3 + nbytes] = fmt, nbytes % 256, nbytes // 256, mpdu, mcs
     exp = torch.from_numpy(blob).to(dev)
     idx = torch.arange(n_frames, device=dev)
     tx_info = {"ms": tx_ms, "Msamples_per_s": nss * n_frames * L / tx_ms / 1e3, "frames": n_frames,
@@ -147,9 +156,9 @@ MIXED_KINDS = [(0, 0, 94), (0, 4, 300), (0, 7, 1000), (1, 0, 200), (1, 5, 800), 
                (2, 8, 1496)]  # (format, mcs, MPDU bytes); the first is the shape of the reference's own IQ fixture
 
 
-def build_corpus_mixed(torch, ctx, tx, n_frames, seed, dev, snr_db=30.0):
-    """Frames of MIXED_KINDS in rotation, each with its own payload, back to back with 64-sample gaps, made by
-    the GPU transmitter.  Returns the tuple of build_corpus_gpu plus totals for the rate figures."""
+def payloads_mixed(tx, n_frames, seed):
+    """PSDU bytes and expected PDU blobs of the mixed corpus `seed`: a function of (frames, seed) alone (see
+    payloads_uniform).  Returns (psdu bytes, psdu_off, plen, blob, kind_of, per_kind shells)."""
     import zlib
     rng = np.random.default_rng(80211 + seed)
     kinds = MIXED_KINDS
@@ -157,17 +166,10 @@ def build_corpus_mixed(torch, ctx, tx, n_frames, seed, dev, snr_db=30.0):
     per_kind = []
     for fmt, mcs, nb in kinds:
         shell = np.frombuffer(tx.ampdu_vht([bytes(nb)]), dtype=np.uint8).copy() if fmt == 2 else np.zeros(nb, np.uint8)
-        plen = len(shell)
-        m = tx.Mod(fmt, mcs, 1).set_len(plen)
-        per_kind.append((shell, plen, ctx.tx_samples(fmt, mcs, 1, plen), m.nsym * m.ndbps))
+        per_kind.append((shell, len(shell)))
     kind_of = np.arange(n_frames) % len(kinds)
     plen = np.array([per_kind[k][1] for k in kind_of], dtype=np.int64)
-    nsamp = np.array([per_kind[k][2] for k in kind_of], dtype=np.int64)
-    steps = np.array([per_kind[k][3] for k in kind_of], dtype=np.int64)
-    gap = 64
-    out_off = np.concatenate([[0], np.cumsum(nsamp + gap)[:-1]]) + gap
     psdu_off = np.concatenate([[0], np.cumsum(plen)[:-1]])
-    total = int(out_off[-1] + nsamp[-1] + gap)
     psdu = np.zeros(int(plen.sum()), dtype=np.uint8)
     blob = np.zeros((n_frames, maxb + 4), dtype=np.uint8)
     for k, (fmt, mcs, nb) in enumerate(kinds):
@@ -183,6 +185,24 @@ def build_corpus_mixed(torch, ctx, tx, n_frames, seed, dev, snr_db=30.0):
         blob[rows, 0], blob[rows, 1], blob[rows, 2] = fmt, nb % 256, nb // 256
         blob[rows, 3:3 + nb] = mpdu
         blob[rows, 3 + nb] = mcs
+    return psdu, psdu_off, plen, blob, kind_of
+
+
+def build_corpus_mixed(torch, ctx, tx, n_frames, seed, dev, snr_db=30.0):
+    """Frames of MIXED_KINDS in rotation, each with its own payload, back to back with 64-sample gaps, made by
+    the GPU transmitter.  Returns the tuple of build_corpus_gpu plus totals for the rate figures."""
+    kinds = MIXED_KINDS
+    psdu, psdu_off, plen, blob, kind_of = payloads_mixed(tx, n_frames, seed)
+    per_kind = []
+    for fmt, mcs, nb in kinds:
+        pl = len(tx.ampdu_vht([bytes(nb)])) if fmt == 2 else nb
+        m = tx.Mod(fmt, mcs, 1).set_len(pl)
+        per_kind.append((None, pl, ctx.tx_samples(fmt, mcs, 1, pl), m.nsym * m.ndbps))
+    nsamp = np.array([per_kind[k][2] for k in kind_of], dtype=np.int64)
+    steps = np.array([per_kind[k][3] for k in kind_of], dtype=np.int64)
+    gap = 64
+    out_off = np.concatenate([[0], np.cumsum(nsamp + gap)[:-1]]) + gap
+    total = int(out_off[-1] + nsamp[-1] + gap)
     d = ctx.make_tx_desc(n_frames)
     d["out_off"], d["psdu_off"], d["psdu_len"] = out_off, psdu_off, plen
     d["format"] = np.array([kinds[k][0] for k in kind_of])
@@ -256,25 +276,37 @@ def cpu_baseline(arena_host, arena1_host, sync, navail, n_sample, gpu_blobs, bud
     dtn = time.perf_counter() - t0
     n_done = sum(p[0] for p in parts)
     samples = sum(p[1] for p in parts)
+    # `frames`, `fcs_ok` and `gpu_mismatches` all describe the threaded leg, the one `value` is measured on; the
+    # single-thread leg (a subset of the same frames, run first) has its own three figures
     return dict(value=samples / dtn / 1e6, unit="Msamples/s", cores=cores, kind="port",
                 sample="first %d frames of the benchmark corpus (%d samples) sharded over %d threads of the CPU "
                        "oracle, %.1f s; one thread alone: %d frames in %.1f s" % (n_done, samples, cores, dtn, d1[0], dt1),
-                single_thread_value=d1[1] / dt1 / 1e6, frames=n_done + d1[0],
-                fcs_ok=sum(p[3] for p in parts), gpu_mismatches=sum(p[2] for p in parts) + d1[2])
+                frames=n_done, fcs_ok=sum(p[3] for p in parts), gpu_mismatches=sum(p[2] for p in parts),
+                single_thread_value=d1[1] / dt1 / 1e6,
+                single_thread={"frames": d1[0], "fcs_ok": d1[3], "gpu_mismatches": d1[2]})
 
 
-def measured_traffic(workload, n):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/*_traffic.json), if they were taken on this workload and batch size."""
-    path = os.path.join(ROOT, "profiles", "traffic.json")
+def measured_counters(workload, n):
+    """Per-launch hardware counters of the dominant kernels from the committed rocprofv3 passes
+    (profiles/counters.json, written by tools/make_counters_json.py from the pass summaries beside it), if they were
+    taken on this workload and batch size; None otherwise."""
+    path = os.path.join(ROOT, "profiles", "counters.json")
     try:
         with open(path) as f:
             t = json.load(f)
         if t.get("workload") == workload and t.get("frames") == n:
-            return t.get("k_decode_hbm_bytes_per_launch")
+            return t
     except (OSError, ValueError):
         pass
     return None
+
+
+VECTOR_FP32_PEAK_TFLOPS = 157.3   # MI355X vector fp32 peak (256 CUs x 4 SIMDs x 32 lanes x 2 flop (FMA) x 2.4 GHz)
+FLOP_PER_STATE_UPDATE = 3.0       # two float adds and one compare-select per trellis state and step (lib/decode_impl.cc:242-258)
+# SIMD-cycles per wave-wide state update of the decoder's instruction mix at the issue rates measured on this chip
+# (tools/ubench/valu2.hip: v_add/v_sub 2.1, v_max/v_alignbit 4.1 per instruction at saturation; 1.5 adds + sub + max +
+# alignbit per update): the floor the kernel is priced against
+MIX_FLOOR_CYCLES = 14.6
 
 
 def main():
@@ -344,20 +376,38 @@ def main():
     gatherer = shard.PduGather(n, out_stride, dev, dst=0, depth=depth) if world > 1 else None
     counter = [0]
 
+    # At N > 1 the kernels and the collective share one explicit torch stream: the library launches on the stream it
+    # is handed (never on the context's own stream, whose order against the collective would only follow from the
+    # legacy default stream's implicit synchronisation), RCCL's gather is ordered behind whatever that stream holds
+    # when it is started, and wait() makes the same stream wait for the collective before a slot is reused.
+    side = torch.cuda.Stream(device=dev) if world > 1 else None
+    gathered = [None]
+
     def step():
         slot = counter[0] % depth
         counter[0] += 1
         o, ol, npd = outs[slot]
-        if gatherer is not None:
-            gatherer.wait(slot)  # the batch that used these tensors two steps ago has left
-        ctx.rx_batch_into(arena, arena1, desc, n, o, ol, npd)
-        if gatherer is not None:
-            # the one exchange step of the path: decoded MPDUs travel to rank 0 (RCCL gather over xGMI)
-            gatherer.start(slot, o, ol)
+        if side is None:
+            ctx.rx_batch_into(arena, arena1, desc, n, o, ol, npd)
+            return
+        with torch.cuda.stream(side):
+            assert ctx._stream().value, "the library must be handed the side stream, not its own"
+            if gatherer is not None:
+                gatherer.wait(slot)  # the batch that used these tensors two steps ago has left
+            ctx.rx_batch_into(arena, arena1, desc, n, o, ol, npd)
+            if gatherer is not None:
+                # the one exchange step of the path: decoded MPDUs travel to rank 0 (RCCL gather over xGMI)
+                gatherer.start(slot, o, ol)
 
     def fence():
         if gatherer is not None:
-            gatherer.finish()
+            if side is not None:
+                with torch.cuda.stream(side):
+                    last = gatherer.finish()
+            else:
+                last = gatherer.finish()
+            if last[0] is not None:
+                gathered[0] = last
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -389,6 +439,33 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         value_local = float(tt.item())
         gatherer = saved
+
+    # ---- N > 1: what arrived on rank 0 is checked rank by rank against the MPDUs that rank's corpus was made from
+    # (the corpora are functions of the rank: rank 0 rebuilds every rank's expected PDUs)
+    gather_check = None
+    if world > 1 and rank == 0 and gathered[0] is not None:
+        out_all, len_all = gathered[0]
+        per_rank = []
+        for r in range(world):
+            if args.workload == MIXED:
+                exp_r = payloads_mixed(tx, n, r)[3]
+            elif args.unique > 0:
+                exp_r = None  # the replicated corpus keeps its payloads on the rank that drew them
+            else:
+                exp_r = payloads_uniform(args.workload, n, r)[1]
+            rows = out_all[r * n:(r + 1) * n]
+            lens = len_all[r * n:(r + 1) * n]
+            got = (lens > 0)
+            rec = {"rank": r, "fcs_ok": int(got.sum().item())}
+            if exp_r is not None:
+                e = torch.from_numpy(exp_r).to(rows.device)
+                m = (rows[:, :e.shape[1]] == e).all(dim=1)
+                rec["bit_exact_vs_tx"] = int((got & m).sum().item())
+                rec["fcs_ok_but_wrong"] = int((got & ~m).sum().item())
+            per_rank.append(rec)
+        gather_check = {"ranks": per_rank, "slots_per_rank": n, "slot_bytes": out_stride,
+                        "note": "the PDU slots rank 0 holds after the last gather of the timed region, "
+                                "compared with the MPDUs each rank's corpus was generated from"}
 
     # ---- correctness of what was just timed
     n_ok = int(n_pdu.sum().item())
@@ -472,10 +549,14 @@ def main():
                    "format": "VHT" if fmt == 2 else "HT" if fmt == 1 else "L" if fmt == 0 else "L/HT/VHT in rotation",
                    "mcs": mcs if extra is None else [list(k) for k in MIXED_KINDS], "n_rx": nss,
                    "psdu_bytes": nbytes + 4 if fmt == 2 else nbytes, "snr_db": snr_db, "unique_payloads": args.unique if args.unique > 0 else n,
-                   "parallelism": "frames sharded per GPU, RCCL gather of MPDUs" if world > 1 else "single GPU"},
+                   "parallelism": ("frames sharded per rank, gather of MPDUs to rank 0 over %s" %
+                                   ("RCCL" if backend == "nccl" else backend + " (host-staged rehearsal, ranks share GPUs)"))
+                   if world > 1 else "single GPU"},
         "psdu": {"frames": n, "fcs_ok": n_ok, "bit_exact_vs_tx": bitexact, "fcs_ok_but_wrong": wrong},
         "kernel_ms": timing,
     }
+    if gather_check is not None:
+        res["gathered_on_rank0"] = gather_check
     if value_local is not None:
         res["without_gather"] = {"value": samples_per_step * args.steps / value_local / 1e6, "unit": "Msamples/s",
                                  "ms_per_step": value_local / args.steps * 1e3,
@@ -494,29 +575,60 @@ def main():
     dec_ms = timing.get("viterbi", 0.0) + timing.get("traceback", 0.0)
     if dec_ms > 0:
         timing["decode"] = dec_ms
-        achieved = b_alg * n / (dec_ms * 1e-3) / 1e9
+        dur = dec_ms * 1e-3
         steps_per_frame = TRELLIS_STEPS[args.workload] if extra is None else extra["total_steps"] / n
-        res["roofline"] = {"bound": "hbm", "kernel": "k_decode", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                           "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                           "traffic": measured_traffic(args.workload, n),
-                           "algorithmic_bytes_per_frame": b_alg,
-                           "note": "k_decode is bound by VALU issue of the 64-state add-compare-select recursion, "
-                                   "not by HBM; it also reads the materialised soft bits and writes/reads the "
-                                   "survivor words, which the per-frame figure (IQ in + PSDU out) does not count",
-                           "acs_state_updates_per_s": 64.0 * steps_per_frame * n / (dec_ms * 1e-3)}
-        # VALU issue, the resource that does bound k_decode: one wave instruction updates one state of 64
-        # frames; the add/add/sub/max/alignbit mix costs 14.6 SIMD-cycles per wave-wide state update at the
-        # instruction rates measured on this chip (tools/ubench), on 1024 SIMDs at 2.4 GHz
+        updates = 64.0 * steps_per_frame * n                       # trellis state updates of the launch, as the path defines them
+        ctr = measured_counters(args.workload, n)
+        kd = (ctr or {}).get("k_decode", {})
+        traffic = None
+        if "FETCH_SIZE_KiB" in kd and "WRITE_SIZE_KiB" in kd:
+            # gfx950 tallies the 128-byte read requests of wide streaming loads at 64 bytes: FETCH_SIZE is doubled
+            traffic = 2.0 * kd["FETCH_SIZE_KiB"] * 1024.0 + kd["WRITE_SIZE_KiB"] * 1024.0
+        hbm = b_alg * n / dur / 1e9
+        tflops = FLOP_PER_STATE_UPDATE * updates / dur / 1e12
+        # The kernel is bound by vector-instruction issue of the add-compare-select recursion, not by memory: the
+        # record is priced against the vector fp32 peak (adds, a subtract and a maximum per update; nothing in it can
+        # be an FMA, so half of that peak is the most any schedule of it could reach), the HBM figures stay beside it.
+        res["roofline"] = {"bound": "valu", "kernel": "k_decode", "achieved": tflops, "peak": VECTOR_FP32_PEAK_TFLOPS,
+                           "unit": "TFLOP/s", "frac": tflops / VECTOR_FP32_PEAK_TFLOPS, "traffic": traffic,
+                           "flop_per_state_update": FLOP_PER_STATE_UPDATE,
+                           "acs_state_updates_per_s": updates / dur,
+                           "kernel_ms": dec_ms,
+                           "hbm": {"achieved": hbm, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm / HBM_PEAK_GBS,
+                                   "algorithmic_bytes_per_frame": b_alg, "traffic_bytes_per_launch": traffic,
+                                   "traffic_over_algorithmic": (traffic / (b_alg * n)) if traffic else None,
+                                   "note": "IQ in + PSDU out per frame; the launch also reads the soft bits the "
+                                           "demodulator materialised and writes and reads the survivor words"}}
+        # vector-instruction issue, the resource that binds: every figure but the last two comes from counters of
+        # the profiled launch (rocprofv3 passes under profiles/, same workload and batch size) and from this run's
+        # own kernel duration
         wave_updates = 64.0 * steps_per_frame * ((n + 63) // 64) if extra is None else float(extra["total_steps"])
-        cyc = 1024 * 2.4e9 * dec_ms * 1e-3 / wave_updates
-        res["roofline"]["valu_issue"] = {"simd_cycles_per_wave_state_update": cyc, "floor": 14.6, "frac": 14.6 / cyc}
+        vi = {"wave_state_updates": wave_updates}
+        if "SQ_INSTS_VALU" in kd and "GRBM_GUI_ACTIVE" in kd and kd.get("duration_ns", 0) > 0:
+            clk = kd["GRBM_GUI_ACTIVE"] / 8.0 / kd["duration_ns"]          # GHz: the counter sums the 8 XCDs
+            simd_cycles = 1024.0 * clk * 1e9 * dur
+            vi.update({"source": ctr.get("source"), "valu_insts_per_launch": kd["SQ_INSTS_VALU"],
+                       "valu_insts_per_wave_state_update": kd["SQ_INSTS_VALU"] / wave_updates,
+                       "clock_ghz_under_load": clk,
+                       "issue_slots_used_frac": 2.0 * kd["SQ_INSTS_VALU"] / simd_cycles,
+                       "simd_cycles_per_wave_state_update": simd_cycles / wave_updates})
+            if "SQ_WAVE_CYCLES" in kd and "SQ_WAIT_ANY" in kd:
+                vi["wave_cycles_waiting_frac"] = kd["SQ_WAIT_ANY"] / kd["SQ_WAVE_CYCLES"]
+        else:
+            vi["simd_cycles_per_wave_state_update"] = 1024 * 2.4e9 * dur / wave_updates
+            vi["note"] = "no counter pass for this workload and batch size: cycles at the nominal 2.4 GHz"
+        vi["mix_floor_cycles"] = MIX_FLOOR_CYCLES
+        vi["frac_of_mix_floor"] = MIX_FLOOR_CYCLES / vi["simd_cycles_per_wave_state_update"]
+        res["roofline"]["valu_issue"] = vi
         if extra is None and timing.get("demod", 0.0) > 0:
             # the kernel of the path that HBM does bound: samples in, soft bits out
             nsym, nrx, nllr = DEMOD_SHAPE[args.workload]
             b_demod = nsym * 80 * 8 * nrx + 4 * nllr
             ach = b_demod * n / (timing["demod"] * 1e-3) / 1e9
+            km = (ctr or {}).get("k_demod", {})
+            tr = (2.0 * km["FETCH_SIZE_KiB"] + km["WRITE_SIZE_KiB"]) * 1024.0 if "FETCH_SIZE_KiB" in km and "WRITE_SIZE_KiB" in km else None
             res["roofline"]["k_demod"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                          "frac": ach / HBM_PEAK_GBS, "algorithmic_bytes_per_frame": b_demod}
+                                          "frac": ach / HBM_PEAK_GBS, "algorithmic_bytes_per_frame": b_demod, "traffic": tr}
     if rank == 0 and world == 1 and args.detect and extra is None:
         # raw capture in: frame detection (presiso -> trigger -> sync) finds the frames, `signal`'s trigger search
         # picks the ones it deals with, then the same RX kernels run; reported beside the headline, which starts

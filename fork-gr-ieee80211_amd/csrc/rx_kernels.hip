@@ -159,14 +159,16 @@ struct SigBits {
     __device__ __forceinline__ unsigned operator[](int i) const { return (unsigned)((w >> i) & 1ull); }
 };
 
+// CRC-8 of the SIG fields: x^8 + x^2 + x + 1 (0x07), register preset to ones, field bits fed in order
+// (IEEE 802.11-2016 19.3.9.4.4; genCrc8Bits / checkBitCrc8, lib/cloud80211phy.cc:1329-1403).
+__device__ __forceinline__ unsigned crc8_step(unsigned c, unsigned bit)
+{
+    return ((c << 1) & 0xffu) ^ ((((c >> 7) ^ bit) & 1u) ? 0x07u : 0u);
+}
 __device__ __forceinline__ unsigned crc8_run(SigBits in, int n)
 {
     unsigned c = 0xff;
-    for (int i = 0; i < n; i++) {
-        c <<= 1;
-        if (c & 0x100) c = (c + 1) ^ 0x06;
-        if (in[i]) c ^= 0x07;
-    }
+    for (int i = 0; i < n; i++) c = crc8_step(c, in[i]);
     return c;
 }
 __device__ __forceinline__ bool crc8_check(SigBits in, int n)  // the CRC's eight bits follow the n it covers
@@ -1055,6 +1057,17 @@ __device__ __forceinline__ void tone_slots(int (&kI)[4], int (&kQ)[4], const int
     }
 }
 
+// A symbol whose samples are all zero (the capture ends inside the frame, digital silence) has a pilot sum of zero,
+// and the reference's arithmetic then makes every soft bit of it 0 * 0 / 0; a tone whose channel estimate is zero
+// gives infinities.  Such soft bits leave as 0.0, i.e. as erasures: the decoder's path metrics stay finite.
+__device__ __forceinline__ void erase_unless(bool ok, float &a, float &b, float &c, float &d)
+{
+    a = ok ? a : 0.0f;
+    b = ok ? b : 0.0f;
+    c = ok ? c : 0.0f;
+    d = ok ? d : 0.0f;
+}
+
 // Soft bits of one tone -> the symbol's LDS stage.
 __device__ __forceinline__ void put_llrs(float *stage, c32 q, int mod, float scale, int nb, int nax,
                                          const int (&kI)[4], const int (&kQ)[4])
@@ -1063,6 +1076,9 @@ __device__ __forceinline__ void put_llrs(float *stage, c32 q, int mod, float sca
     float li0, li1, li2, li3, lq0, lq1, lq2, lq3;
     axis_llr(q.x, nax, li0, li1, li2, li3);
     axis_llr(q.y, nax, lq0, lq1, lq2, lq3);
+    // every soft bit of an axis is a finite function of the axis value, so one test per axis covers them
+    erase_unless(__builtin_isfinite(q.x), li0, li1, li2, li3);
+    erase_unless(__builtin_isfinite(q.y), lq0, lq1, lq2, lq3);
     stage[kI[0]] = li0;
     if (nb >= 2) {
         stage[kQ[0]] = lq0;
@@ -1510,12 +1526,8 @@ __device__ __forceinline__ uint32_t crc_byte(uint32_t c, uint32_t byte, const ui
 __device__ __forceinline__ bool delimiter_ok(uint32_t d)
 {
     unsigned c = 0xff;
-    for (int i = 0; i < 16; i++) {
-        c <<= 1;
-        if (c & 0x100) c = (c + 1) ^ 0x06;
-        if ((d >> i) & 1u) c ^= 0x07;
-    }
-    c = 0xff - (c & 0xff);
+    for (int i = 0; i < 16; i++) c = crc8_step(c, (d >> i) & 1u);
+    c = 0xff - c;
     unsigned r = 0;
     for (int i = 0; i < 8; i++) r |= ((c >> (7 - i)) & 1u) << i;
     return ((d >> 16) & 0xffu) == r && (d >> 24) == 0x4Eu;

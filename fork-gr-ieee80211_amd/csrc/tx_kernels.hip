@@ -54,16 +54,13 @@ __device__ __forceinline__ c32 wave_idft64(c32 x, int lane)
 __device__ __forceinline__ int bin_to_tone(int b) { return b < 32 ? b : b - 64; }
 __device__ __forceinline__ int pilot_index(int b) { return b == 43 ? 0 : b == 57 ? 1 : b == 7 ? 2 : b == 21 ? 3 : -1; }
 
-// CRC-8 of the SIG fields (IEEE 802.11-2016 19.3.9.4.4), bits given LSB first in v.
+// CRC-8 of the SIG fields (IEEE 802.11-2016 19.3.9.4.4): x^8 + x^2 + x + 1, register preset to ones, the ones'
+// complement sent; bits given LSB first in v.
 __device__ int crc8_bits(unsigned long long v, int n)
 {
     int c = 0xff;
-    for (int i = 0; i < n; i++) {
-        c <<= 1;
-        if (c & 0x100) c = (c + 1) ^ 0x06;
-        if ((v >> i) & 1) c ^= 0x07;
-    }
-    c = 0xff - (c & 0xff);
+    for (int i = 0; i < n; i++) c = ((c << 1) & 0xff) ^ ((((c >> 7) ^ (int)(v >> i)) & 1) ? 0x07 : 0);
+    c = 0xff - c;
     // transmitted c7 first: bit i of the result is the i-th transmitted bit
     int r = 0;
     for (int i = 0; i < 8; i++) r |= ((c >> (7 - i)) & 1) << i;

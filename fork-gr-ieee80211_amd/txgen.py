@@ -101,14 +101,12 @@ class Mod:
 
 # ----------------------------------------------------------------------------- bit-level pieces
 def crc8_bits(bits):
+    """CRC-8 of the SIG fields and A-MPDU delimiters: x^8 + x^2 + x + 1, register preset to ones, bits fed most
+    significant first, the ones' complement sent (IEEE 802.11-2016 19.3.9.4.4)."""
     c = 0xFF
     for b in bits:
-        c <<= 1
-        if c & 0x100:
-            c = (c + 1) ^ 0x06
-        if b:
-            c ^= 0x07
-    c = 0xFF - (c & 0xFF)
+        c = ((c << 1) & 0xFF) ^ (0x07 if ((c >> 7) ^ (1 if b else 0)) & 1 else 0)
+    c = 0xFF - c
     return [(c >> (7 - i)) & 1 for i in range(8)]
 
 

@@ -987,6 +987,13 @@ int orc_demod(const float *in0_ri, const float *in1_ri, int navail, float rad, o
             }
         }
     }
+    /* Convention of the batch boundary, not of the reference: a data symbol whose samples are all zero (the capture
+     * ends inside the frame; the reference's `signal` would still be waiting for those samples, lib/signal_impl.cc:
+     * 164-192) has a pilot sum of zero and the arithmetic above makes its soft bits 0 * 0 / 0; a tone with a zero
+     * channel estimate gives infinities.  Such soft bits are handed on as 0.0, i.e. as erasures, here and in the
+     * GPU demodulator alike. */
+    for (int i = 0; i < f->total; i++)
+        if (!isfinite(llr[i])) llr[i] = 0.0f;
 done:
     free(c);
     return f->status;

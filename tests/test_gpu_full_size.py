@@ -14,8 +14,8 @@ sys.path.insert(0, ROOT)
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("workload,n_oracle", [("vht_mcs4_1500B_snr30", 24), ("ht_mcs15_2x2_1500B_snr30", 24),
-                                               ("vht_mcs8_1500B_snr30", 24)])
+@pytest.mark.parametrize("workload,n_oracle", [("l_mcs0_1000B_snr30", 12), ("vht_mcs4_1500B_snr30", 24),
+                                               ("ht_mcs15_2x2_1500B_snr30", 24), ("vht_mcs8_1500B_snr30", 24)])
 def test_configured_batch_round_trip(pkg, rxctx, oracle, workload, n_oracle):
     import torch
     import bench
@@ -119,3 +119,72 @@ def test_mixed_capture_corpus_replicated(pkg, rxctx, oracle, two_ant, n_frames):
     assert torch.equal(out_len, exp_len.to(dev)[idx])
     assert torch.equal(out, exp.to(dev)[idx])
     assert int(n_pdu.sum().item()) == n_frames
+
+
+def test_mixed_workload_of_the_benchmark(pkg, rxctx, oracle):
+    """The benchmark's own mixed corpus at its configured size (125 000 legacy / HT / VHT frames of nine rates and
+    lengths in rotation, made by the GPU transmitter, a different payload in every frame, 30 dB): every frame whose
+    FCS passes carries exactly its MPDU, nearly all pass, and the oracle agrees on a sample of every kind."""
+    import torch
+    import bench
+    dev = torch.device("cuda", 0)
+    n = bench.DEFAULT_FRAMES[bench.MIXED]
+    arenas, sync, navail, exp, idx, L, tx_info, extra = bench.build_corpus_mixed(torch, rxctx, pkg.txgen, n, 0, dev)
+    desc = torch.from_numpy(rxctx.make_desc(sync, navail).view(np.uint8).reshape(-1)).to(dev)
+    blob_len = exp.shape[1]
+    stride = ((blob_len + 4 + 63) // 64) * 64
+    out = torch.zeros((n, stride), dtype=torch.uint8, device=dev)
+    out_len = torch.zeros(n, dtype=torch.int32, device=dev)
+    n_pdu = torch.zeros(n, dtype=torch.int32, device=dev)
+    rxctx.rx_batch_into(arenas[0], None, desc, n, out, out_len, n_pdu)
+    rxctx.sync()
+    ok = n_pdu == 1
+    match = (out[:, :blob_len] == exp).all(dim=1)
+    assert int((ok & ~match).sum().item()) == 0 and int((n_pdu > 1).sum().item()) == 0
+    assert int(ok.sum().item()) >= int(0.999 * n)
+    kinds = len(bench.MIXED_KINDS)
+    want_len = torch.tensor([k[2] + 4 for k in bench.MIXED_KINDS], dtype=torch.int32, device=dev)[torch.arange(n, device=dev) % kinds]
+    assert bool((out_len[ok] == want_len[ok]).all().item()) and bool((out_len[~ok] == 0).all().item())
+    lens = out_len.cpu().numpy()
+    a0 = arenas[0]
+    for i in list(range(kinds)) + list(range(n - 2 * kinds, n, 2)) + [n // 2, n // 3]:
+        s, e = int(sync[i]) - 176, int(sync[i]) + int(navail[i])
+        ref = oracle.rx_frame(a0[s:e].cpu().numpy(), None, 176, 0.0, want_llr=False)
+        assert bytes(out[i, : lens[i]].cpu().numpy()) == ref["blob"], int(i)
+
+
+def test_raw_capture_at_the_headline_size(pkg, rxctx, oracle):
+    """gr80211_rx_capture (detection -> trigger search -> RX) over the headline corpus as one raw capture: 100 000 VHT
+    MCS8 frames back to back, 392 M samples.  Every frame the trigger search keeps is decoded as the oracle chain
+    decodes it from the detected position (a sample of them is run), FCS passes carry the transmitted MPDU, and
+    the count of frames is the corpus's."""
+    import torch
+    import bench
+    dev = torch.device("cuda", 0)
+    wl = "vht_mcs8_1500B_snr30"
+    n = bench.DEFAULT_FRAMES[wl]
+    arenas, sync, navail, exp, idx, L, tx_info = bench.build_corpus_gpu(torch, rxctx, pkg.txgen, wl, n, 0, dev)
+    blob_len = exp.shape[1]
+    stride = ((blob_len + 4 + 63) // 64) * 64
+    r = rxctx.rx_capture(arenas[0], None, max_frames=2 * n, out_stride=stride)
+    rxctx.sync()
+    nf = r["n"]
+    assert abs(nf - n) <= n // 500
+    d = r["desc"][: nf * 32].cpu().numpy().view(pkg.rx.FRAME_DESC_DTYPE)
+    so = d["sync_off"].astype(np.int64)
+    fidx = np.clip(so // L, 0, n - 1)
+    okd = (r["n_pdu"][:nf] == 1)
+    md = (r["out"][:nf, :blob_len] == exp[torch.from_numpy(fidx).to(dev)]).all(dim=1)
+    assert int((okd & ~md).sum().item()) == 0
+    assert int(okd.sum().item()) >= int(0.998 * n)
+    # the positions found are the nominal ones within the cyclic-prefix margin
+    assert np.abs(so - (fidx * L + 176)).max() <= 8
+    lens = r["out_len"][:nf].cpu().numpy()
+    host = arenas[0]
+    for j in np.unique(np.linspace(0, nf - 1, 40).astype(np.int64)):
+        s = int(so[j]) - 176 - 8
+        e = int(so[j]) + int(d["n_avail"][j])
+        e = min(e, int(so[j]) + 224 + 3920)   # what `signal` forwards of this frame: no later frame's samples
+        seg = host[max(s, 0):e].cpu().numpy()
+        ref = oracle.rx_frame(seg, None, int(so[j]) - max(s, 0), float(d["rad"][j]), want_llr=False)
+        assert bytes(r["out"][j, : lens[j]].cpu().numpy()) == ref["blob"], int(j)

@@ -205,6 +205,87 @@ def test_garbage_and_truncated_frames_dropped(pkg, rxctx, oracle):
     assert r[0]["n_pdu"] == 0 and r[1]["n_pdu"] == 0 and r[2]["status"] == 1
 
 
+def test_symbols_without_samples_are_erasures(pkg, rxctx, oracle):
+    """Data symbols whose samples are exactly zero -- a capture that ends inside the frame, silence written into the
+    middle of one -- make the reference's arithmetic produce 0 * 0 / 0 for every soft bit of the symbol.  Both the
+    GPU demodulator and the oracle hand such soft bits on as 0.0 (erasures), so everything stays comparable: soft
+    bits, decoded bits, PDUs."""
+    import torch
+    tx = pkg.txgen
+    rng = np.random.default_rng(26)
+    frames = []
+    for fmt, mcs, nss, nbytes in ((2, 4, 1, 400), (0, 5, 1, 300), (1, 12, 2, 500), (2, 8, 2, 900), (1, 7, 1, 1200)):
+        fr, _ = make_noisy(tx, rng, fmt, mcs, nss, nbytes, 35.0)
+        ants, sidx = fr
+        n = len(ants[0])
+        hole = [a.copy() for a in ants]
+        for a in hole:
+            a[n // 2: n // 2 + 400] = 0      # five whole symbols of silence in the middle
+        frames.append((hole, sidx))
+        frames.append(([a[: n - 30 - 200] for a in ants], sidx))   # the capture ends 200 samples before the frame does
+        frames.append(([a[: n - 30 - 60] for a in ants], sidx))    # only part of the last symbol is missing
+    for two in (False, True):
+        sel = [f for f in frames if (len(f[0]) == 2) == two]
+        r = run_rx(pkg, rxctx, oracle, sel, check_llr=True)
+        assert all(ref["status"] == 0 for ref in r)
+        assert all(np.all(np.isfinite(ref["llr"])) for ref in r)
+        assert any(np.count_nonzero(ref["llr"] == 0.0) >= ref["frame"].m.nCBPS for ref in r)
+        # decoded bits as well: the oracle's decoder on its soft bits against the GPU decoder on the same stream
+        for ref in r:
+            f = ref["frame"]
+            desc = np.zeros(1, dtype=pkg.rx.DEC_DESC_DTYPE)
+            desc[0] = (0, f.total, f.m.format, f.m.len, f.m.cr, f.m.mcs, f.m.ampdu, f.trellis, 0)
+            res = rxctx.decode_batch(torch.from_numpy(ref["llr"]).cuda(), desc, 1, want_bits=True)
+            rxctx.sync()
+            want = oracle.decode(ref["llr"], f.m.format, f.m.len, f.m.cr, f.m.mcs, f.m.ampdu, f.trellis, want_bits=True)
+            got = np.unpackbits(res["bits"][0].cpu().numpy(), bitorder="little")[: f.trellis]
+            assert np.array_equal(got, want["bits"])
+
+
+def test_decoder_given_non_finite_soft_bits(pkg, rxctx, oracle):
+    """Soft bits that are NaN or infinite can only come from a caller of gr80211_decode_batch (the demodulator never
+    emits them).  The reference's compare `a > b` and this decoder's max / sign-of-difference treat a NaN metric
+    differently, so the bits of such a frame are not defined; what is: nothing faults, the frame publishes nothing
+    it should not (a PDU only ever leaves with a good FCS), and the other frames of the batch -- the same decoder
+    group, lane = frame -- are decoded exactly as without it."""
+    import zlib
+    import torch
+    from test_gpu_decode import coded_frame
+    tx = pkg.txgen
+    rng = np.random.default_rng(27)
+    good = [coded_frame(tx, rng, fmt, cr, int(rng.integers(60, 700))) for fmt in (0, 2) for cr in range(4) for _ in range(4)]
+    bad = []
+    for k, f in enumerate(good[:12]):
+        g = dict(f)
+        llr = f["llr"].copy()
+        llr[rng.integers(0, len(llr), 40)] = (np.nan, np.inf, -np.inf)[k % 3]
+        if k % 4 == 0:
+            llr[:] = np.nan
+        g["llr"] = llr
+        bad.append(g)
+    frames = [x for pair in zip(good, bad + good[12:]) for x in pair]
+    is_bad = [False, True] * 12 + [False] * (len(frames) - 24)
+    desc = np.zeros(len(frames), dtype=pkg.rx.DEC_DESC_DTYPE)
+    off, parts = 0, []
+    for i, f in enumerate(frames):
+        desc[i] = (off, len(f["llr"]), f["fmt"], f["len"], f["cr"], f["mcs"], f["ampdu"], f["trellis"], 0)
+        parts.append(f["llr"])
+        off += len(f["llr"])
+    res = rxctx.decode_batch(torch.from_numpy(np.concatenate(parts)).cuda(), desc, len(frames), want_bits=True)
+    rxctx.sync()
+    out, out_len, n_pdu = res["out"].cpu().numpy(), res["out_len"].cpu().numpy(), res["n_pdu"].cpu().numpy()
+    bits = res["bits"].cpu().numpy()
+    for i, f in enumerate(frames):
+        if is_bad[i]:
+            for p in pkg.rx.split_pdus(bytes(out[i, : out_len[i]])):
+                body = p["mpdu"]
+                assert zlib.crc32(body[:-4]) == int.from_bytes(body[-4:], "little")
+            continue
+        want = oracle.decode(f["llr"], f["fmt"], f["len"], f["cr"], f["mcs"], f["ampdu"], f["trellis"], want_bits=True)
+        assert np.array_equal(np.unpackbits(bits[i], bitorder="little")[: f["trellis"]], want["bits"]), i
+        assert int(n_pdu[i]) == want["n_pdu"] == 1 and bytes(out[i, : out_len[i]]) == want["blob"], i
+
+
 def test_short_guard_interval_is_a_stride_only(pkg, rxctx, oracle):
     """Short-GI frames: the reference steps 72 samples per data symbol but keeps its 8-sample window offset and
     the long-GI channel estimate (lib/cloud80211phy.cc:898-902, 1155-1159), so it does not recover the payload.
