@@ -57,6 +57,12 @@ struct gr80211_ctx {
     uint32_t *det_totals_h = nullptr;  // pinned
     SchedTotals *totals_h = nullptr;  // pinned
     gr80211_dec_desc *na_desc_h = nullptr;  // pinned: descriptors of gr80211_decode_batch_noalloc on their way to the GPU
+    Buf sel_index;                          // gr80211_rx_resume: which of the frames of the last gr80211_signal_batch go on
+    int signal_n = 0;                       // frames of the last gr80211_signal_batch whose records and channels are still held
+    bool signal_two = false;                // ... and whether it ran on two antennas
+    static constexpr int N_MARK = 256;
+    hipEvent_t mark_ev[N_MARK] = {};        // gr80211_marker_*: created on first use
+    long long mark_next = 0;
     int ampdu_strict = 0;  // de-aggregate A-MPDUs by the standard's rules instead of the reference's
     uint32_t mu_pos = 0;  // MU group position written into the descriptors frame detection makes
     bool profiling = false;
@@ -157,8 +163,70 @@ int finish_timing(gr80211_ctx *c, hipStream_t s)
     return GR80211_OK;
 }
 
+// What the scheduler kernels will report for a batch, worked out on the host from what the host knows of the frames
+// (their decoder tags), so that work buffers can be sized -- or a batch refused -- without waiting for the device:
+// the frames the decoder admits (k_desc_to_info / k_sched_hist), counted per code rate and 64-step length bin and
+// cut into groups of 64 in that order.  The group count and the soft-bit count are exact; a group runs as many steps
+// as its longest frame, which is at most the longest frame of the last bin it takes frames from, so the survivor and
+// bit words are upper bounds.  get(i, &admitted, &cr, &trellis, &soft_bits): soft_bits counts towards llr_floats
+// whether or not the frame is admitted (the demodulator writes them for every frame it keeps).
+template <class Get>
+SchedTotals host_schedule(int n, Get get)
+{
+    static thread_local uint32_t cnt[4][SCHED_NB];
+    static thread_local int32_t longest[4][SCHED_NB];
+    memset(cnt, 0, sizeof(cnt));
+    memset(longest, 0, sizeof(longest));
+    SchedTotals t = {};
+    for (int i = 0; i < n; i++) {
+        bool admitted = false;
+        int cr = 0, trellis = 0;
+        long long soft = 0;
+        get(i, &admitted, &cr, &trellis, &soft);
+        t.llr_floats += (uint64_t)(soft > 0 ? soft : 0);
+        if (!admitted) continue;
+        t.n_valid++;
+        cnt[cr][trellis / 64]++;
+        if (trellis > longest[cr][trellis / 64]) longest[cr][trellis / 64] = trellis;
+    }
+    for (int cr = 0; cr < 4; cr++) {
+        const int cs = chunk_steps(cr);
+        uint32_t in_group = 0;
+        int top = 0;
+        auto close = [&] {
+            const int steps = (top + cs - 1) / cs * cs;
+            t.dec_words += (uint64_t)steps * 128u;
+            t.bits_words += (uint64_t)((steps + 31) / 32) * 64u;
+            t.n_groups++;
+            in_group = 0;
+            top = 0;
+        };
+        for (int b = 0; b < SCHED_NB; b++) {
+            uint32_t left = cnt[cr][b];
+            while (left > 0) {
+                const uint32_t take = left < 64 - in_group ? left : 64 - in_group;
+                in_group += take;
+                left -= take;
+                top = longest[cr][b];
+                if (in_group == 64) close();
+            }
+        }
+        if (in_group) close();
+    }
+    return t;
+}
+
+// Decoder admission of a frame given by its tags (k_desc_to_info, k_sched_hist; lib/decode_impl.cc:93,210).
+bool decoder_admits(int cr, int trellis, int len, long long n_llr)
+{
+    if (cr < 0 || cr > 3 || trellis <= 0 || trellis > GR80211_MAX_TRELLIS || len > GR80211_MAX_PSDU) return false;
+    const int P = cr == CR_12 ? 1 : cr == CR_23 ? 2 : cr == CR_34 ? 3 : 5;
+    const int q = trellis / P, rem = trellis % P;
+    return n_llr >= (long long)q * (P + 1) + (rem ? rem + 1 : 0);
+}
+
 // Shared tail, first half: the scheduler's kernels and the copy of its totals to the host, all asynchronous.
-int launch_sched_stage(gr80211_ctx *c, hipStream_t s, int n, bool from_iq)
+int launch_sched_stage(gr80211_ctx *c, hipStream_t s, int n, bool from_iq, SchedCaps caps = SCHED_NO_CAPS)
 {
     if (c->pending.active) return fail(c, GR80211_ERR_ARG, "a batch submitted with gr80211_rx_submit is waiting for gr80211_rx_finish");
     const int slot_cap = n + 4 * 64 + 64;
@@ -173,29 +241,32 @@ int launch_sched_stage(gr80211_ctx *c, hipStream_t s, int n, bool from_iq)
 
     launch_schedule(info, n, from_iq ? 1 : 0, (int32_t *)c->slot_frame.p, slot_cap, (GroupInfo *)c->groups.p,
                     group_cap, (SchedTotals *)c->totals_d.p, (uint32_t *)c->sched_ws.p,
-                    (unsigned long long *)c->blk_llr.p, s);
+                    (unsigned long long *)c->blk_llr.p, caps, s);
     mark(c, 2, s);
     HIP_TRY(c, hipMemcpyAsync(c->totals_h, c->totals_d.p, sizeof(SchedTotals), hipMemcpyDeviceToHost, s));
     return GR80211_OK;
 }
 
-// Shared tail, second half: waits for the scheduler's totals (they size the work buffers), then (demod) -> viterbi ->
-// traceback.
+// Shared tail, second half: waits for the scheduler's totals (they size the work buffers) unless the caller knows
+// them already (`known`: group and soft-bit counts exact, survivor and bit words upper bounds), then (demod) ->
+// viterbi -> traceback.
 int finish_decode_stages(gr80211_ctx *c, hipStream_t s, int n, bool from_iq, const void *d_iq0, const void *d_iq1,
                          uint64_t arena_len, const gr80211_frame_desc *d_desc, const float *d_llr_in, uint8_t *d_out,
                          int out_stride, int32_t *d_out_len, int32_t *d_n_pdu, uint8_t *d_bits, int bits_stride, bool decode,
-                         const float **llr_used, uint64_t *llr_floats)
+                         const float **llr_used, uint64_t *llr_floats, const SchedTotals *known = nullptr)
 {
     int rc;
     gr80211_frame_info *info = (gr80211_frame_info *)c->info.p;
-    HIP_TRY(c, hipStreamSynchronize(s));
-    const SchedTotals tot = *c->totals_h;
+    if (!known) HIP_TRY(c, hipStreamSynchronize(s));
+    const SchedTotals tot = known ? *known : *c->totals_h;
     if (tot.n_groups < 0) return fail(c, GR80211_ERR_ARG, "scheduler capacity exceeded");
 
+    // a batch launched without waiting for the scheduler hands its kernels the scheduler's record on the device
+    const SchedTotals *dt = known ? (const SchedTotals *)c->totals_d.p : nullptr;
     const float *llr = d_llr_in;
     if (from_iq) {
         if ((rc = ensure(c, c->llr, (size_t)(tot.llr_floats + 64) * sizeof(float)))) return rc;
-        launch_demod(d_iq0, d_iq1, arena_len, d_desc, n, info, c->chan1.p, c->chan2.p, (float *)c->llr.p, s);
+        launch_demod(d_iq0, d_iq1, arena_len, d_desc, n, info, c->chan1.p, c->chan2.p, (float *)c->llr.p, dt, s);
         llr = (const float *)c->llr.p;
     }
     if (llr_used) *llr_used = llr;
@@ -212,23 +283,23 @@ int finish_decode_stages(gr80211_ctx *c, hipStream_t s, int n, bool from_iq, con
             if (gw != 1 && gw != 4) gw = tot.n_groups <= 640 ? 4 : 1;
             if (gw > 1) {
                 launch_viterbi_split(llr, info, (const int32_t *)c->slot_frame.p, (const GroupInfo *)c->groups.p,
-                                     tot.n_groups, (uint32_t *)c->dec.p, s);
+                                     tot.n_groups, (uint32_t *)c->dec.p, dt, s);
                 mark(c, 4, s);
                 launch_traceback((const uint32_t *)c->dec.p, info, (const int32_t *)c->slot_frame.p,
                                  (const GroupInfo *)c->groups.p, tot.n_groups, (uint32_t *)c->bitsw.p, d_out,
-                                 out_stride, d_out_len, d_n_pdu, d_bits, bits_stride, c->ampdu_strict, s);
+                                 out_stride, d_out_len, d_n_pdu, d_bits, bits_stride, c->ampdu_strict, dt, s);
             } else if (c->split_decode) {
                 launch_viterbi(llr, info, (const int32_t *)c->slot_frame.p, (const GroupInfo *)c->groups.p,
-                               tot.n_groups, (uint32_t *)c->dec.p, s);
+                               tot.n_groups, (uint32_t *)c->dec.p, dt, s);
                 mark(c, 4, s);
                 launch_traceback((const uint32_t *)c->dec.p, info, (const int32_t *)c->slot_frame.p,
                                  (const GroupInfo *)c->groups.p, tot.n_groups, (uint32_t *)c->bitsw.p, d_out,
-                                 out_stride, d_out_len, d_n_pdu, d_bits, bits_stride, c->ampdu_strict, s);
+                                 out_stride, d_out_len, d_n_pdu, d_bits, bits_stride, c->ampdu_strict, dt, s);
             } else {
                 // one kernel: the timing slot of the forward pass then covers the traceback as well
                 launch_decode(llr, info, (const int32_t *)c->slot_frame.p, (const GroupInfo *)c->groups.p,
                               tot.n_groups, (uint32_t *)c->dec.p, (uint32_t *)c->bitsw.p, d_out, out_stride,
-                              d_out_len, d_n_pdu, d_bits, bits_stride, c->ampdu_strict, s);
+                              d_out_len, d_n_pdu, d_bits, bits_stride, c->ampdu_strict, dt, s);
                 mark(c, 4, s);
             }
         } else {
@@ -246,12 +317,25 @@ int finish_decode_stages(gr80211_ctx *c, hipStream_t s, int n, bool from_iq, con
 int run_decode_stages(gr80211_ctx *c, hipStream_t s, int n, bool from_iq, const void *d_iq0, const void *d_iq1,
                       uint64_t arena_len, const gr80211_frame_desc *d_desc, const float *d_llr_in, uint8_t *d_out, int out_stride,
                       int32_t *d_out_len, int32_t *d_n_pdu, uint8_t *d_bits, int bits_stride, bool decode,
-                      const float **llr_used, uint64_t *llr_floats)
+                      const float **llr_used, uint64_t *llr_floats, const SchedTotals *known = nullptr)
 {
-    int rc = launch_sched_stage(c, s, n, from_iq);
-    if (rc) return rc;
+    int rc;
+    SchedCaps caps = SCHED_NO_CAPS;
+    if (known) {
+        // the work buffers reach the size the host worked out before the scheduler runs, and the scheduler is told
+        // what there is: should the device arrive at more (the host was told wrong), the batch is not run
+        if (from_iq && (rc = ensure(c, c->llr, (size_t)(known->llr_floats + 64) * sizeof(float)))) return rc;
+        if (decode && known->n_groups > 0) {
+            if ((rc = ensure(c, c->dec, (size_t)(known->dec_words + 128) * sizeof(uint32_t)))) return rc;
+            if ((rc = ensure(c, c->bitsw, (size_t)(known->bits_words + 64) * sizeof(uint32_t)))) return rc;
+        }
+        if (from_iq) caps.llr_floats = c->llr.cap / sizeof(float) - 64;
+        caps.dec_words = decode ? (c->dec.cap >= 128 * sizeof(uint32_t) ? c->dec.cap / sizeof(uint32_t) - 128 : 0) : ~0ull;
+        caps.bits_words = decode ? (c->bitsw.cap >= 64 * sizeof(uint32_t) ? c->bitsw.cap / sizeof(uint32_t) - 64 : 0) : ~0ull;
+    }
+    if ((rc = launch_sched_stage(c, s, n, from_iq, caps))) return rc;
     return finish_decode_stages(c, s, n, from_iq, d_iq0, d_iq1, arena_len, d_desc, d_llr_in, d_out, out_stride, d_out_len,
-                                d_n_pdu, d_bits, bits_stride, decode, llr_used, llr_floats);
+                                d_n_pdu, d_bits, bits_stride, decode, llr_used, llr_floats, known);
 }
 
 int stage_desc(gr80211_ctx *c, hipStream_t s, const void *desc, size_t bytes, unsigned flags, Buf &dst, const void **out)
@@ -274,6 +358,7 @@ int front_end(gr80211_ctx *c, hipStream_t s, const void *d_iq0, const void *d_iq
     int rc;
     const void *dd = nullptr;
     if (c->pending.active) return fail(c, GR80211_ERR_ARG, "a batch submitted with gr80211_rx_submit is waiting for gr80211_rx_finish");
+    c->signal_n = 0;  // the frame records and channels of an earlier gr80211_signal_batch are about to be overwritten
     if ((rc = stage_desc(c, s, desc, (size_t)n * sizeof(gr80211_frame_desc), flags, c->desc, &dd))) return rc;
     if ((rc = ensure(c, c->info, (size_t)n * sizeof(gr80211_frame_info)))) return rc;
     if ((rc = ensure(c, c->chan1, (size_t)n * 64 * 8))) return rc;
@@ -398,8 +483,10 @@ void gr80211_destroy(gr80211_ctx *c)
     for (Buf *b : {&c->desc, &c->ddesc, &c->info, &c->chan1, &c->chan2, &c->llr, &c->slot_frame, &c->groups, &c->dec,
                    &c->bitsw, &c->totals_d, &c->sched_ws, &c->blk_llr, &c->det_mask, &c->det_blk, &c->det_runs,
                    &c->det_rec, &c->det_totals_d, &c->cap_desc, &c->cap_ws, &c->tx_desc, &c->sig_desc, &c->chanl, &c->out_off,
-                   &c->info_alt, &c->chan1_alt, &c->chan2_alt})
+                   &c->info_alt, &c->chan1_alt, &c->chan2_alt, &c->sel_index})
         release(*b);
+    for (auto &e : c->mark_ev)
+        if (e) (void)hipEventDestroy(e);
     if (c->totals_h) (void)hipHostFree(c->totals_h);
     if (c->det_totals_h) (void)hipHostFree(c->det_totals_h);
     if (c->na_desc_h) (void)hipHostFree(c->na_desc_h);
@@ -574,6 +661,8 @@ int gr80211_signal_batch(gr80211_ctx *c, const void *d_iq0, const void *d_iq1, u
     if (rc) return rc;
     HIP_TRY(c, hipMemcpyAsync(d_info, c->info.p, (size_t)n * sizeof(gr80211_frame_info), hipMemcpyDeviceToDevice, s));
     HIP_TRY(c, hipGetLastError());
+    c->signal_n = n;
+    c->signal_two = d_iq1 != nullptr;
     return GR80211_OK;
 }
 
@@ -688,6 +777,7 @@ int gr80211_decode_batch(gr80211_ctx *c, const float *d_llr, uint64_t llr_floats
     int rc;
     const void *dd = nullptr;
     if ((rc = stage_desc(c, s, desc, (size_t)n * sizeof(gr80211_dec_desc), flags, c->ddesc, &dd))) return rc;
+    c->signal_n = 0;
     if ((rc = ensure(c, c->info, (size_t)n * sizeof(gr80211_frame_info)))) return rc;
     mark(c, 0, s);
     launch_desc_to_info((const gr80211_dec_desc *)dd, n, llr_floats, (gr80211_frame_info *)c->info.p, s);
@@ -741,54 +831,21 @@ int gr80211_decode_batch_noalloc(gr80211_ctx *c, const float *d_llr, uint64_t ll
     const size_t bits_bytes = (size_t)1 << 20;
     const size_t dec_bytes = NA_SCRATCH_BYTES - fixed_part - bits_bytes;
 
-    // What the scheduler kernels will ask for, worked out here from the descriptors so that a batch beyond the array
-    // is refused before anything is launched: the frames the decoder admits (k_desc_to_info, k_sched_hist), counted
-    // per code rate and 64-step length bin, cut into groups of 64 in that order; a group runs as many steps as its
-    // longest frame, which is at most the longest frame of the last bin it takes frames from.
-    {
-        static thread_local uint16_t cnt[4][SCHED_NB];
-        static thread_local int32_t longest[4][SCHED_NB];
-        memset(cnt, 0, sizeof(cnt));
-        memset(longest, 0, sizeof(longest));
-        for (int i = 0; i < n; i++) {
-            const gr80211_dec_desc &d = h_desc[i];
-            if (d.cr < 0 || d.cr > 3 || d.trellis <= 0 || d.trellis > GR80211_MAX_TRELLIS || d.len > GR80211_MAX_PSDU) continue;
-            const int P = d.cr == CR_12 ? 1 : d.cr == CR_23 ? 2 : d.cr == CR_34 ? 3 : 5;
-            const int q = d.trellis / P, rem = d.trellis % P;
-            if (d.n_llr < q * (P + 1) + (rem ? rem + 1 : 0)) continue;
-            cnt[d.cr][d.trellis / 64]++;
-            if (d.trellis > longest[d.cr][d.trellis / 64]) longest[d.cr][d.trellis / 64] = d.trellis;
-        }
-        uint64_t dec_words = 0, bits_words = 0;
-        for (int cr = 0; cr < 4; cr++) {
-            const int cs = chunk_steps(cr);
-            int in_group = 0, top = 0;
-            auto close = [&] {
-                const int steps = (top + cs - 1) / cs * cs;
-                dec_words += (uint64_t)steps * 128u;
-                bits_words += (uint64_t)((steps + 31) / 32) * 64u;
-                in_group = 0;
-                top = 0;
-            };
-            for (int b = 0; b < SCHED_NB; b++) {
-                int left = cnt[cr][b];
-                while (left > 0) {
-                    const int take = left < 64 - in_group ? left : 64 - in_group;
-                    in_group += take;
-                    left -= take;
-                    top = longest[cr][b];
-                    if (in_group == 64) close();
-                }
-            }
-            if (in_group) close();
-        }
-        if ((dec_words + 128) * sizeof(uint32_t) > dec_bytes || (bits_words + 64) * sizeof(uint32_t) > bits_bytes) {
-            char msg[200];
-            snprintf(msg, sizeof(msg),
-                     "gr80211_decode_batch_noalloc: the batch needs %llu bytes of survivor words, the scratch array holds %llu",
-                     (unsigned long long)((dec_words + 128) * sizeof(uint32_t)), (unsigned long long)dec_bytes);
-            return fail(c, GR80211_ERR_ARG, msg);
-        }
+    // what the scheduler kernels will ask for, worked out here so that a batch beyond the array is refused before
+    // anything is launched
+    const SchedTotals need = host_schedule(n, [&](int i, bool *admitted, int *cr, int *trellis, long long *soft) {
+        const gr80211_dec_desc &d = h_desc[i];
+        *admitted = decoder_admits(d.cr, d.trellis, d.len, d.n_llr);
+        *cr = d.cr;
+        *trellis = d.trellis;
+        *soft = 0;
+    });
+    if ((need.dec_words + 128) * sizeof(uint32_t) > dec_bytes || (need.bits_words + 64) * sizeof(uint32_t) > bits_bytes) {
+        char msg[200];
+        snprintf(msg, sizeof(msg),
+                 "gr80211_decode_batch_noalloc: the batch needs %llu bytes of survivor words, the scratch array holds %llu",
+                 (unsigned long long)((need.dec_words + 128) * sizeof(uint32_t)), (unsigned long long)dec_bytes);
+        return fail(c, GR80211_ERR_ARG, msg);
     }
 
     HIP_TRY(c, hipSetDevice(c->device));
@@ -830,6 +887,154 @@ int gr80211_decode_batch_noalloc(gr80211_ctx *c, const float *d_llr, uint64_t ll
                                bits_stride, true, nullptr, nullptr);
     if (rc) return rc;
     return finish_timing(c, s);
+}
+
+int gr80211_rx_resume(gr80211_ctx *c, const void *d_iq0, const void *d_iq1, uint64_t arena_len, const gr80211_frame_desc *h_desc,
+                      const int32_t *h_index, const gr80211_frame_info *h_info, int n, uint8_t *d_out, int out_stride,
+                      int32_t *d_out_len, int32_t *d_n_pdu, gr80211_frame_info *d_info, void *stream)
+{
+    if (!c) return GR80211_ERR_ARG;
+    if (int rc_busy = refuse_if_pending(c, "gr80211_rx_resume")) return rc_busy;
+    if (n == 0) return GR80211_OK;
+    if (!d_iq0 || !h_desc || !h_index || !h_info || n < 0 || !d_out || !d_out_len || !d_n_pdu || out_stride < 8)
+        return fail(c, GR80211_ERR_ARG, "gr80211_rx_resume: bad argument");
+    if (c->signal_n <= 0) return fail(c, GR80211_ERR_ARG, "gr80211_rx_resume: the context holds no results of gr80211_signal_batch");
+    if (c->signal_two != (d_iq1 != nullptr)) return fail(c, GR80211_ERR_ARG, "gr80211_rx_resume: antenna count differs from gr80211_signal_batch");
+    if (n > c->signal_n) return fail(c, GR80211_ERR_ARG, "gr80211_rx_resume: more frames than gr80211_signal_batch saw");
+    for (int i = 0; i < n; i++)
+        if (h_index[i] < 0 || h_index[i] >= c->signal_n) return fail(c, GR80211_ERR_ARG, "gr80211_rx_resume: index outside the signal batch");
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = pick(c, stream);
+    int rc;
+    // the scheduler's totals from the records the caller holds: exact group and soft-bit counts, bounds for the rest
+    const SchedTotals known = host_schedule(n, [&](int i, bool *admitted, int *cr, int *trellis, long long *soft) {
+        const gr80211_frame_info &fi = h_info[h_index[i]];
+        const bool ok = fi.status == GR80211_ST_OK;
+        *admitted = ok && !(fi.len > GR80211_MAX_PSDU || fi.trellis > GR80211_MAX_TRELLIS || fi.trellis <= 0 || fi.cr < 0 || fi.cr > 3);
+        *cr = fi.cr;
+        *trellis = fi.trellis;
+        *soft = ok ? (fi.total > 0 ? fi.total : 0) : 0;
+    });
+    if ((rc = ensure(c, c->desc, (size_t)n * sizeof(gr80211_frame_desc)))) return rc;
+    if ((rc = ensure(c, c->sel_index, (size_t)n * sizeof(int32_t)))) return rc;
+    if ((rc = ensure(c, c->info_alt, (size_t)n * sizeof(gr80211_frame_info)))) return rc;
+    if ((rc = ensure(c, c->chan1_alt, (size_t)n * 64 * 8))) return rc;
+    if (d_iq1 && (rc = ensure(c, c->chan2_alt, (size_t)n * 520 * 8))) return rc;
+    HIP_TRY(c, hipMemcpyAsync(c->desc.p, h_desc, (size_t)n * sizeof(gr80211_frame_desc), hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(c->sel_index.p, h_index, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    mark(c, 0, s);
+    // the preamble has run over these frames already: their records and channels move to the front of the second
+    // set of buffers, which takes the first set's place
+    launch_pre_gather((const int32_t *)c->sel_index.p, n, (const gr80211_frame_info *)c->info.p, c->chan1.p,
+                      d_iq1 ? c->chan2.p : nullptr, (gr80211_frame_info *)c->info_alt.p, c->chan1_alt.p, c->chan2_alt.p, s);
+    std::swap(c->info, c->info_alt);
+    std::swap(c->chan1, c->chan1_alt);
+    if (d_iq1) std::swap(c->chan2, c->chan2_alt);
+    c->signal_n = 0;
+    mark(c, 1, s);
+    rc = run_decode_stages(c, s, n, true, d_iq0, d_iq1, arena_len, (const gr80211_frame_desc *)c->desc.p, nullptr, d_out, out_stride,
+                           d_out_len, d_n_pdu, nullptr, 0, true, nullptr, nullptr, &known);
+    if (rc) return rc;
+    if (d_info)
+        HIP_TRY(c, hipMemcpyAsync(d_info, c->info.p, (size_t)n * sizeof(gr80211_frame_info), hipMemcpyDeviceToDevice, s));
+    return finish_timing(c, s);
+}
+
+int gr80211_last_batch_refused(gr80211_ctx *c)
+{
+    // the scheduler's record of the last batch, as its copy to the host left it (the stream must have run it)
+    if (!c || !c->totals_h) return GR80211_ERR_ARG;
+    return c->totals_h->n_groups < 0 ? 1 : 0;
+}
+
+int gr80211_copy_h2d_async(gr80211_ctx *c, void *d_dst, const void *h_src, size_t bytes, void *stream)
+{
+    if (!c) return GR80211_ERR_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, pick(c, stream)));
+    return GR80211_OK;
+}
+
+int gr80211_copy_d2h_async(gr80211_ctx *c, void *h_dst, const void *d_src, size_t bytes, void *stream)
+{
+    if (!c) return GR80211_ERR_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, pick(c, stream)));
+    return GR80211_OK;
+}
+
+int gr80211_copy_d2d_async(gr80211_ctx *c, void *d_dst, const void *d_src, size_t bytes, void *stream)
+{
+    if (!c) return GR80211_ERR_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, pick(c, stream)));
+    return GR80211_OK;
+}
+
+int gr80211_stream_idle(gr80211_ctx *c, void *stream)
+{
+    if (!c) return GR80211_ERR_ARG;
+    const hipError_t e = hipStreamQuery(pick(c, stream));
+    if (e == hipSuccess) return 1;
+    if (e == hipErrorNotReady) return 0;
+    return fail(c, GR80211_ERR_HIP, "hipStreamQuery", e);
+}
+
+int gr80211_stream_wait(gr80211_ctx *c, void *stream, gr80211_ctx *other, void *other_stream)
+{
+    if (!c || !other) return GR80211_ERR_ARG;
+    if (c->device != other->device) return fail(c, GR80211_ERR_ARG, "gr80211_stream_wait: contexts of different devices");
+    HIP_TRY(c, hipSetDevice(c->device));
+    // ev[6] is not one of the profiling events
+    HIP_TRY(c, hipEventRecord(other->ev[6], pick(other, other_stream)));
+    HIP_TRY(c, hipStreamWaitEvent(pick(c, stream), other->ev[6], 0));
+    return GR80211_OK;
+}
+
+long long gr80211_marker_record(gr80211_ctx *c, void *stream)
+{
+    if (!c) return GR80211_ERR_ARG;
+    if (hipSetDevice(c->device) != hipSuccess) return fail(c, GR80211_ERR_HIP, "hipSetDevice");
+    const long long id = c->mark_next;
+    hipEvent_t &e = c->mark_ev[id % gr80211_ctx::N_MARK];
+    if (!e) {
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return fail(c, GR80211_ERR_HIP, "hipEventCreate");
+    } else if (hipEventSynchronize(e) != hipSuccess) {  // the marker N_MARK records back gives up its place
+        return fail(c, GR80211_ERR_HIP, "hipEventSynchronize");
+    }
+    if (hipEventRecord(e, pick(c, stream)) != hipSuccess) return fail(c, GR80211_ERR_HIP, "hipEventRecord");
+    c->mark_next = id + 1;
+    return id;
+}
+
+int gr80211_marker_done(gr80211_ctx *c, long long id, int wait)
+{
+    if (!c || id < 0 || id >= c->mark_next) return GR80211_ERR_ARG;
+    if (id < c->mark_next - gr80211_ctx::N_MARK) return 1;  // its place went to a later marker, which waited for it first
+    hipEvent_t e = c->mark_ev[id % gr80211_ctx::N_MARK];
+    if (wait) {
+        HIP_TRY(c, hipEventSynchronize(e));
+        return 1;
+    }
+    const hipError_t r = hipEventQuery(e);
+    if (r == hipSuccess) return 1;
+    if (r == hipErrorNotReady) return 0;
+    return fail(c, GR80211_ERR_HIP, "hipEventQuery", r);
+}
+
+int gr80211_host_register(gr80211_ctx *c, void *p, size_t bytes)
+{
+    if (!c || !p || !bytes) return GR80211_ERR_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipHostRegister(p, bytes, hipHostRegisterDefault));
+    return GR80211_OK;
+}
+
+int gr80211_host_unregister(gr80211_ctx *c, void *p)
+{
+    if (!c || !p) return GR80211_ERR_ARG;
+    HIP_TRY(c, hipHostUnregister(p));
+    return GR80211_OK;
 }
 
 int gr80211_tx_samples(int format, int mcs, int nss, int psdu_len)

@@ -24,6 +24,13 @@ struct SchedTotals {
     int32_t n_valid;
 };
 
+// Room the caller has for what the scheduler lays out (soft bits, survivor words, decoded-bit words).  A batch that
+// needs more is not run: the scheduler reports n_groups = -1 and every later kernel of the batch leaves at once.
+struct SchedCaps {
+    uint64_t llr_floats, dec_words, bits_words;
+};
+constexpr SchedCaps SCHED_NO_CAPS = {~0ull, ~0ull, ~0ull};
+
 constexpr int SCHED_NB = 513;  // trellis-length bins of 64 steps
 constexpr int SCHED_WS_WORDS = 4 * SCHED_NB + 8;  // scheduler scratch: bin counters, rate starts, valid count
 
@@ -42,24 +49,35 @@ void launch_signal_copy(const void *iq0, const void *iq1, uint64_t arena_len, co
 void launch_desc_to_info(const gr80211_dec_desc *desc, int n, uint64_t llr_floats, gr80211_frame_info *info, hipStream_t s);
 void launch_schedule(gr80211_frame_info *info, int n, int assign_llr, int32_t *slot_frame, int slot_cap,
                      GroupInfo *groups, int group_cap, SchedTotals *totals, uint32_t *ws, unsigned long long *blk_llr,
-                     hipStream_t s);
+                     SchedCaps caps, hipStream_t s);
 void launch_pre_gather(const int32_t *path, int n, const gr80211_frame_info *info_in, const void *chan1_in,
                        const void *chan2_in, gr80211_frame_info *info_out, void *chan1_out, void *chan2_out, hipStream_t s);
+// `totals` (the scheduler's record on the device) lets the kernels of a batch that was launched without waiting for
+// the scheduler see what it decided: a batch it refused (n_groups < 0) is not run, and no group beyond its count is.
 void launch_demod(const void *iq0, const void *iq1, uint64_t arena_len, const gr80211_frame_desc *desc, int n,
                   const gr80211_frame_info *info, const void *chan1, const void *chan2, float *llr,
-                  hipStream_t s);
+                  const SchedTotals *totals, hipStream_t s);
 void launch_viterbi(const float *llr, const gr80211_frame_info *info, const int32_t *slot_frame,
-                    const GroupInfo *groups, int n_groups, uint32_t *dec, hipStream_t s);
+                    const GroupInfo *groups, int n_groups, uint32_t *dec, const SchedTotals *totals, hipStream_t s);
 void launch_traceback(const uint32_t *dec, const gr80211_frame_info *info, const int32_t *slot_frame,
                       const GroupInfo *groups, int n_groups, uint32_t *bitsw, uint8_t *out, int out_stride,
-                      int32_t *out_len, int32_t *n_pdu, uint8_t *bits_out, int bits_stride, int strict, hipStream_t s);
+                      int32_t *out_len, int32_t *n_pdu, uint8_t *bits_out, int bits_stride, int strict,
+                      const SchedTotals *totals, hipStream_t s);
 // Forward pass with four wavefronts per group, for batches too small to fill the chip with one wave per group;
 // same survivor words as launch_viterbi, to be followed by launch_traceback.
 void launch_viterbi_split(const float *llr, const gr80211_frame_info *info, const int32_t *slot_frame,
-                          const GroupInfo *groups, int n_groups, uint32_t *dec, hipStream_t s);
+                          const GroupInfo *groups, int n_groups, uint32_t *dec, const SchedTotals *totals, hipStream_t s);
 void launch_decode(const float *llr, const gr80211_frame_info *info, const int32_t *slot_frame,
                    const GroupInfo *groups, int n_groups, uint32_t *dec, uint32_t *bitsw, uint8_t *out, int out_stride,
-                   int32_t *out_len, int32_t *n_pdu, uint8_t *bits_out, int bits_stride, int strict, hipStream_t s);
+                   int32_t *out_len, int32_t *n_pdu, uint8_t *bits_out, int bits_stride, int strict,
+                   const SchedTotals *totals, hipStream_t s);
+// Groups a decoder kernel may run: the launch's count, cut to what the scheduler reports on the device.
+__device__ __forceinline__ int groups_to_run(int n_groups, const SchedTotals *totals)
+{
+    if (!totals) return n_groups;
+    const int t = totals->n_groups;
+    return t < n_groups ? (t < 0 ? 0 : t) : n_groups;
+}
 #ifdef GR80211_TIMELINE
 int read_timeline(unsigned long long *dst, int n_groups);
 #endif

@@ -845,11 +845,12 @@ __global__ __launch_bounds__(SCHED_BLOCK) void k_sched_hist(gr80211_frame_info *
 __global__ __launch_bounds__(1024) void k_sched_scan(uint32_t *__restrict__ ws, unsigned long long *__restrict__ blk_llr,
                                                      int nblk, int assign_llr, int slot_cap, int group_cap,
                                                      int32_t *__restrict__ slot_frame, GroupInfo *__restrict__ groups,
-                                                     SchedTotals *__restrict__ totals)
+                                                     SchedTotals *__restrict__ totals, unsigned long long llr_cap)
 {
     __shared__ unsigned long long part[1024];
     __shared__ uint32_t binpart[1024];
     __shared__ uint32_t crs[5];
+    __shared__ int s_over;
     const int tid = threadIdx.x;
     // --- LLR block sums
     const int per = (nblk + 1023) / 1024;
@@ -870,6 +871,7 @@ __global__ __launch_bounds__(1024) void k_sched_scan(uint32_t *__restrict__ ws, 
         unsigned long long run = 0;
         for (int k = 0; k < 1024; k++) { const unsigned long long v = part[k]; part[k] = run; run += v; }
         totals->llr_floats = assign_llr ? run : 0;
+        s_over = assign_llr && run > llr_cap;  // more soft bits than the caller has room for
         // SCHED_NB = 513 bins per rate = 171 threads per rate
         uint32_t p = 0, cnt = 0;
         for (int cr = 0; cr < 4; cr++) {
@@ -893,10 +895,9 @@ __global__ __launch_bounds__(1024) void k_sched_scan(uint32_t *__restrict__ ws, 
     }
     const int n_slots = (int)crs[4];
     const int n_groups = n_slots / 64;
-    if (tid == 0) {
-        totals->n_groups = (n_slots > slot_cap || n_groups > group_cap) ? -1 : n_groups;
-    }
-    if (n_slots > slot_cap || n_groups > group_cap) return;
+    const bool refuse = n_slots > slot_cap || n_groups > group_cap || s_over;
+    if (tid == 0) totals->n_groups = refuse ? -1 : n_groups;
+    if (refuse) return;
     for (int sl = tid; sl < n_slots; sl += 1024) slot_frame[sl] = -1;
     for (int g = tid; g < n_groups; g += 1024) {
         const uint32_t s0 = (uint32_t)g * 64u;
@@ -962,7 +963,8 @@ __global__ __launch_bounds__(SCHED_BLOCK) void k_sched_assign(gr80211_frame_info
     }
 }
 
-__global__ __launch_bounds__(1024) void k_sched_groups(GroupInfo *__restrict__ groups, SchedTotals *__restrict__ totals)
+__global__ __launch_bounds__(1024) void k_sched_groups(GroupInfo *__restrict__ groups, SchedTotals *__restrict__ totals,
+                                                       unsigned long long dec_cap, unsigned long long bits_cap)
 {
     __shared__ unsigned long long part[1024];
     __shared__ unsigned long long part2[1024];
@@ -995,6 +997,7 @@ __global__ __launch_bounds__(1024) void k_sched_groups(GroupInfo *__restrict__ g
         }
         totals->dec_words = r1;
         totals->bits_words = r2;
+        if (r1 > dec_cap || r2 > bits_cap) totals->n_groups = -1;  // no room for the survivor or bit words: not run
     }
     __syncthreads();
     unsigned long long r1 = part[tid], r2 = part2[tid];
@@ -1147,10 +1150,11 @@ __global__ __launch_bounds__(64 * DEMOD_WAVES) void k_demod(const c32 *__restric
                                                             const gr80211_frame_desc *__restrict__ descs, int n,
                                                             const gr80211_frame_info *__restrict__ info,
                                                             const c32 *__restrict__ chan1, const c32 *__restrict__ chan2,
-                                                            float *__restrict__ llr)
+                                                            float *__restrict__ llr, const SchedTotals *__restrict__ totals)
 {
     const int f = blockIdx.x;
     if (f >= n) return;
+    if (totals && totals->n_groups < 0) return;  // the scheduler refused the batch: its soft bits have no place
     const int st = info[f].status;
     if (!(st == GR80211_ST_OK || st == GR80211_ST_DROP_DECODE_LIMIT)) return;
     if ((info[f].nSS == 1) != (NSS == 1)) return;
@@ -1493,10 +1497,10 @@ __device__ __forceinline__ void viterbi_group(const float *__restrict__ llr, uns
 __global__ __launch_bounds__(64) void k_viterbi(const float *__restrict__ llr, const gr80211_frame_info *__restrict__ info,
                                                 const int32_t *__restrict__ slot_frame,
                                                 const GroupInfo *__restrict__ groups, int n_groups,
-                                                uint32_t *__restrict__ dec)
+                                                uint32_t *__restrict__ dec, const SchedTotals *__restrict__ totals)
 {
     const int g = blockIdx.x;
-    if (g >= n_groups) return;
+    if (g >= groups_to_run(n_groups, totals)) return;
     const int lane = threadIdx.x;
     __shared__ float tile[64 * TILE_STRIDE];
     const GroupInfo gi = groups[g];
@@ -1750,10 +1754,11 @@ __global__ __launch_bounds__(64) void k_traceback(const uint32_t *__restrict__ d
                                                   const GroupInfo *__restrict__ groups, int n_groups,
                                                   uint32_t *__restrict__ bitsw, uint8_t *__restrict__ out, int out_stride,
                                                   int32_t *__restrict__ out_len, int32_t *__restrict__ n_pdu,
-                                                  uint8_t *__restrict__ bits_out, int bits_stride, int strict)
+                                                  uint8_t *__restrict__ bits_out, int bits_stride, int strict,
+                                                  const SchedTotals *__restrict__ totals)
 {
     const int g = blockIdx.x;
-    if (g >= n_groups) return;
+    if (g >= groups_to_run(n_groups, totals)) return;
     const int lane = threadIdx.x;
     __shared__ uint32_t s_crc[256];
     for (int i = lane; i < 256; i += 64) s_crc[i] = c_tab.crc[i];
@@ -1792,10 +1797,11 @@ __global__ __launch_bounds__(64 * WAVES) void k_decode(const float *__restrict__
                                                uint32_t *__restrict__ dec, uint32_t *__restrict__ bitsw,
                                                uint8_t *__restrict__ out, int out_stride, int32_t *__restrict__ out_len,
                                                int32_t *__restrict__ n_pdu, uint8_t *__restrict__ bits_out, int bits_stride,
-                                               int strict)
+                                               int strict, const SchedTotals *__restrict__ totals)
 {
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g0 = blockIdx.x * WAVES + wv;
+    n_groups = groups_to_run(n_groups, totals);
     if (g0 >= n_groups) return;
     // the scheduler numbers the groups of a code rate by rising trellis length; workgroups start in index order, so
     // the numbering is walked backwards and the longest trellises start first (a mixed batch ends 6 % sooner)
@@ -1976,43 +1982,47 @@ void launch_desc_to_info(const gr80211_dec_desc *desc, int n, uint64_t llr_float
 }
 void launch_schedule(gr80211_frame_info *info, int n, int assign_llr, int32_t *slot_frame, int slot_cap,
                      GroupInfo *groups, int group_cap, SchedTotals *totals, uint32_t *ws, unsigned long long *blk_llr,
-                     hipStream_t s)
+                     SchedCaps caps, hipStream_t s)
 {
     const int nblk = (n + SCHED_BLOCK - 1) / SCHED_BLOCK;
     const int nws = SCHED_BINS + 8;
     hipLaunchKernelGGL(k_zero_u32, dim3((nws + 255) / 256), dim3(256), 0, s, ws, nws);
     hipLaunchKernelGGL(k_sched_hist, dim3(nblk), dim3(SCHED_BLOCK), 0, s, info, n, ws, blk_llr);
     hipLaunchKernelGGL(k_sched_scan, dim3(1), dim3(1024), 0, s, ws, blk_llr, nblk, assign_llr, slot_cap, group_cap,
-                       slot_frame, groups, totals);
+                       slot_frame, groups, totals, (unsigned long long)caps.llr_floats);
     hipLaunchKernelGGL(k_sched_assign, dim3(nblk), dim3(SCHED_BLOCK), 0, s, info, n, assign_llr, ws, blk_llr,
                        slot_frame, groups, totals);
-    hipLaunchKernelGGL(k_sched_groups, dim3(1), dim3(1024), 0, s, groups, totals);
+    hipLaunchKernelGGL(k_sched_groups, dim3(1), dim3(1024), 0, s, groups, totals, (unsigned long long)caps.dec_words,
+                       (unsigned long long)caps.bits_words);
 }
 void launch_demod(const void *iq0, const void *iq1, uint64_t arena_len, const gr80211_frame_desc *desc, int n,
-                  const gr80211_frame_info *info, const void *chan1, const void *chan2, float *llr, hipStream_t s)
+                  const gr80211_frame_info *info, const void *chan1, const void *chan2, float *llr,
+                  const SchedTotals *totals, hipStream_t s)
 {
     hipLaunchKernelGGL(k_demod<1>, dim3(n), dim3(256), 0, s, (const c32 *)iq0, (const c32 *)iq1, arena_len, desc, n, info,
-                       (const c32 *)chan1, (const c32 *)chan2, llr);
+                       (const c32 *)chan1, (const c32 *)chan2, llr, totals);
     // two-stream frames only exist where a second antenna does
     if (iq1)
         hipLaunchKernelGGL(k_demod<2>, dim3(n), dim3(256), 0, s, (const c32 *)iq0, (const c32 *)iq1, arena_len, desc, n,
-                           info, (const c32 *)chan1, (const c32 *)chan2, llr);
+                           info, (const c32 *)chan1, (const c32 *)chan2, llr, totals);
 }
 void launch_viterbi(const float *llr, const gr80211_frame_info *info, const int32_t *slot_frame,
-                    const GroupInfo *groups, int n_groups, uint32_t *dec, hipStream_t s)
+                    const GroupInfo *groups, int n_groups, uint32_t *dec, const SchedTotals *totals, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_viterbi, dim3(n_groups), dim3(64), 0, s, llr, info, slot_frame, groups, n_groups, dec);
+    hipLaunchKernelGGL(k_viterbi, dim3(n_groups), dim3(64), 0, s, llr, info, slot_frame, groups, n_groups, dec, totals);
 }
 void launch_traceback(const uint32_t *dec, const gr80211_frame_info *info, const int32_t *slot_frame,
                       const GroupInfo *groups, int n_groups, uint32_t *bitsw, uint8_t *out, int out_stride,
-                      int32_t *out_len, int32_t *n_pdu, uint8_t *bits_out, int bits_stride, int strict, hipStream_t s)
+                      int32_t *out_len, int32_t *n_pdu, uint8_t *bits_out, int bits_stride, int strict,
+                      const SchedTotals *totals, hipStream_t s)
 {
     hipLaunchKernelGGL(k_traceback, dim3(n_groups), dim3(64), 0, s, dec, info, slot_frame, groups, n_groups, bitsw,
-                       out, out_stride, out_len, n_pdu, bits_out, bits_stride, strict);
+                       out, out_stride, out_len, n_pdu, bits_out, bits_stride, strict, totals);
 }
 void launch_decode(const float *llr, const gr80211_frame_info *info, const int32_t *slot_frame,
                    const GroupInfo *groups, int n_groups, uint32_t *dec, uint32_t *bitsw, uint8_t *out, int out_stride,
-                   int32_t *out_len, int32_t *n_pdu, uint8_t *bits_out, int bits_stride, int strict, hipStream_t s)
+                   int32_t *out_len, int32_t *n_pdu, uint8_t *bits_out, int bits_stride, int strict,
+                   const SchedTotals *totals, hipStream_t s)
 {
     // A batch of at most one group per SIMD runs fastest with exactly one wave on every SIMD (a lone wave finishes
     // its trellis in three quarters of the time a paired one needs): workgroups of four waves with two LDS tiles each,
@@ -2021,10 +2031,10 @@ void launch_decode(const float *llr, const gr80211_frame_info *info, const int32
     if (n_groups <= 1024)
         hipLaunchKernelGGL((k_decode<true, DEC_WAVES>), dim3((n_groups + DEC_WAVES - 1) / DEC_WAVES), dim3(64 * DEC_WAVES), 0, s,
                            llr, info, slot_frame, groups, n_groups, dec, bitsw, out, out_stride, out_len, n_pdu, bits_out,
-                           bits_stride, strict);
+                           bits_stride, strict, totals);
     else
         hipLaunchKernelGGL((k_decode<false, 1>), dim3(n_groups), dim3(64), 0, s, llr, info, slot_frame, groups, n_groups, dec,
-                           bitsw, out, out_stride, out_len, n_pdu, bits_out, bits_stride, strict);
+                           bitsw, out, out_stride, out_len, n_pdu, bits_out, bits_stride, strict, totals);
 }
 void launch_ndp_emit(const void *iq0, uint64_t arena_len, const gr80211_frame_desc *desc, int n,
                      const gr80211_frame_info *info, uint8_t *out, int out_stride, int32_t *out_len, int32_t *n_pdu,

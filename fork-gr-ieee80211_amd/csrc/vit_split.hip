@@ -204,10 +204,10 @@ __device__ __forceinline__ void split_dispatch(int wi, const float *llr, unsigne
 __global__ __launch_bounds__(256) void k_viterbi_split(const float *__restrict__ llr, const gr80211_frame_info *__restrict__ info,
                                                        const int32_t *__restrict__ slot_frame,
                                                        const GroupInfo *__restrict__ groups, int n_groups,
-                                                       uint32_t *__restrict__ dec)
+                                                       uint32_t *__restrict__ dec, const SchedTotals *__restrict__ totals)
 {
     const int g = blockIdx.x;
-    if (g >= n_groups) return;  // whole workgroup
+    if (g >= groups_to_run(n_groups, totals)) return;  // whole workgroup
     const int lane = threadIdx.x & 63;
     const int wi = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     __shared__ float tile[64 * TILE_STRIDE];
@@ -228,9 +228,9 @@ __global__ __launch_bounds__(256) void k_viterbi_split(const float *__restrict__
 }  // namespace
 
 void launch_viterbi_split(const float *llr, const gr80211_frame_info *info, const int32_t *slot_frame,
-                          const GroupInfo *groups, int n_groups, uint32_t *dec, hipStream_t s)
+                          const GroupInfo *groups, int n_groups, uint32_t *dec, const SchedTotals *totals, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_viterbi_split, dim3(n_groups), dim3(256), 0, s, llr, info, slot_frame, groups, n_groups, dec);
+    hipLaunchKernelGGL(k_viterbi_split, dim3(n_groups), dim3(256), 0, s, llr, info, slot_frame, groups, n_groups, dec, totals);
 }
 
 }  // namespace gr80211

@@ -71,7 +71,10 @@ EXPORTS = [
     "gr80211_copy_h2d", "gr80211_copy_d2h", "gr80211_set_profiling", "gr80211_last_timing",
     "gr80211_version", "gr80211_table_checksum", "gr80211_tx_samples", "gr80211_tx_batch", "gr80211_set_mu_pos", "gr80211_set_ampdu_strict", "gr80211_tx_mu_batch",
     "gr80211_host_alloc", "gr80211_host_free", "gr80211_copy_d2d", "gr80211_signal_emit_batch", "gr80211_demod_tagged_batch",
-    "gr80211_rx_submit", "gr80211_rx_finish", "gr80211_decode_batch_noalloc",
+    "gr80211_rx_submit", "gr80211_rx_finish", "gr80211_decode_batch_noalloc", "gr80211_rx_resume",
+    "gr80211_last_batch_refused", "gr80211_copy_h2d_async", "gr80211_copy_d2h_async", "gr80211_copy_d2d_async",
+    "gr80211_stream_idle", "gr80211_stream_wait", "gr80211_marker_record", "gr80211_marker_done",
+    "gr80211_host_register", "gr80211_host_unregister",
 ]
 
 _lib = None
@@ -105,6 +108,17 @@ def load_library():
                                       C.POINTER(C.c_uint64), vp]
     L.gr80211_decode_batch.argtypes = [vp, vp, C.c_uint64, vp, C.c_int, C.c_uint, vp, C.c_int, vp, vp, vp,
                                        C.c_int, vp]
+    L.gr80211_rx_resume.argtypes = [vp, vp, vp, C.c_uint64, vp, vp, vp, C.c_int, vp, C.c_int, vp, vp, vp, vp]
+    L.gr80211_last_batch_refused.argtypes = [vp]
+    for name in ("gr80211_copy_h2d_async", "gr80211_copy_d2h_async", "gr80211_copy_d2d_async"):
+        getattr(L, name).argtypes = [vp, vp, vp, C.c_size_t, vp]
+    L.gr80211_stream_idle.argtypes = [vp, vp]
+    L.gr80211_stream_wait.argtypes = [vp, vp, vp, vp]
+    L.gr80211_marker_record.argtypes = [vp, vp]
+    L.gr80211_marker_record.restype = C.c_longlong
+    L.gr80211_marker_done.argtypes = [vp, C.c_longlong, C.c_int]
+    L.gr80211_host_register.argtypes = [vp, vp, C.c_size_t]
+    L.gr80211_host_unregister.argtypes = [vp, vp]
     L.gr80211_decode_batch_noalloc.argtypes = [vp, vp, C.c_uint64, vp, C.c_int, vp, C.c_int, vp, vp, vp, C.c_int, vp]
     L.gr80211_dev_alloc.argtypes = [vp, C.c_size_t]
     L.gr80211_dev_alloc.restype = vp
@@ -282,6 +296,20 @@ class RxContext:
             self.h, C.c_void_p(out.data_ptr()), out.shape[1], C.c_void_p(out_len.data_ptr()),
             C.c_void_p(n_pdu.data_ptr()), C.c_void_p(info.data_ptr()) if info is not None else None)
         self._check(rc, "gr80211_rx_finish")
+
+    def rx_resume(self, iq0, iq1, desc_sel, index_sel, info_all, out, out_len, n_pdu, info=None):
+        """demod + decode for some of the frames the last signal_batch call on this context ran over.  desc_sel:
+        FRAME_DESC_DTYPE ndarray of the kept frames; index_sel: their positions in that call (int32); info_all: the
+        records that call returned (FRAME_INFO_DTYPE ndarray).  Nothing is waited for."""
+        d = np.ascontiguousarray(desc_sel)
+        ix = np.ascontiguousarray(index_sel, dtype=np.int32)
+        ia = np.ascontiguousarray(info_all)
+        rc = self.lib.gr80211_rx_resume(
+            self.h, C.c_void_p(iq0.data_ptr()), C.c_void_p(iq1.data_ptr()) if iq1 is not None else None, iq0.numel(),
+            C.c_void_p(d.ctypes.data), C.c_void_p(ix.ctypes.data), C.c_void_p(ia.ctypes.data), len(ix),
+            C.c_void_p(out.data_ptr()), out.shape[1], C.c_void_p(out_len.data_ptr()), C.c_void_p(n_pdu.data_ptr()),
+            C.c_void_p(info.data_ptr()) if info is not None else None, self._stream())
+        self._check(rc, "gr80211_rx_resume")
 
     def detect(self, iq, max_desc=None):
         """Frame detection over a capture (complex64 CUDA tensor).  Returns (desc tensor on the device as

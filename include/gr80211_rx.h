@@ -191,6 +191,27 @@ int gr80211_rx_finish(gr80211_ctx *ctx, uint8_t *d_out, int out_stride, int32_t 
                       gr80211_frame_info *d_info);
 
 /*
+ * The receive path in the two steps a streaming caller takes anyway, with no wait for the GPU inside either.  Such a
+ * caller (a block with the input contract of ieee80211::signal) first asks what every tagged sync byte starts --
+ * gr80211_signal_batch: L-SIG decision and frame span per sync byte, the work of `signal`'s S_DEMOD state
+ * (lib/signal_impl.cc:108-162) -- reads the records, replays `signal`'s trigger search over them on the host (a frame
+ * hides the sync bytes inside its 224 + nsamp samples, a failed L-SIG 80: lib/signal_impl.cc:75-106,153-160) and then
+ * continues with the frames that search keeps: gr80211_rx_resume = demod/demod2 + decode for frames whose preamble
+ * results the context still holds from that gr80211_signal_batch call (no other batch call in between).
+ * h_desc[i]: descriptor of the i-th kept frame (as given to gr80211_signal_batch, n_avail possibly cut to the frame's
+ * span); h_index[i]: its position in that call; h_info: the caller's host copy of all records that call returned.
+ * The records tell the host what the scheduler kernels will lay out, so the work buffers are sized before anything
+ * is launched and nothing is waited for; outputs as for gr80211_rx_batch.  Should h_info not be what the device holds,
+ * the batch may find less room than it needs: it then publishes nothing (every out_len 0) and
+ * gr80211_last_batch_refused, asked after the stream has run the batch, returns 1.
+ */
+int gr80211_rx_resume(gr80211_ctx *ctx, const void *d_iq0, const void *d_iq1, uint64_t arena_len,
+                      const gr80211_frame_desc *h_desc, const int32_t *h_index, const gr80211_frame_info *h_info,
+                      int n_frames, uint8_t *d_out, int out_stride, int32_t *d_out_len, int32_t *d_n_pdu,
+                      gr80211_frame_info *d_info, void *stream);
+int gr80211_last_batch_refused(gr80211_ctx *ctx);
+
+/*
  * Frame detection over a whole capture: the work of the blocks upstream of `signal` in the reference's receive
  * flowgraph (examples/rx.grc: presiso -> trigger -> sync; examples/presiso.grc:68-137,218-229,
  * lib/trigger_impl.cc:59-117, lib/sync_impl.cc:61-196).  d_iq: complex64 samples of the (first) antenna.
@@ -344,6 +365,29 @@ void gr80211_dev_free(gr80211_ctx *ctx, void *p);
 int gr80211_copy_h2d(gr80211_ctx *ctx, void *d_dst, const void *h_src, size_t bytes, void *stream);
 int gr80211_copy_d2h(gr80211_ctx *ctx, void *h_dst, const void *d_src, size_t bytes, void *stream);
 int gr80211_copy_d2d(gr80211_ctx *ctx, void *d_dst, const void *d_src, size_t bytes, void *stream); /* no overlap */
+/*
+ * The same copies without the wait at the end, and what a single host thread needs to keep several contexts' copies
+ * and kernels in flight (GNU Radio gives a block one thread; no counterpart in the reference, whose blocks compute on
+ * that thread).  Host memory of an asynchronous copy must be page-locked (gr80211_host_alloc, gr80211_host_register)
+ * and stay untouched until the copy has run.
+ *   gr80211_stream_idle    1 if the stream has run everything enqueued on it, 0 if not (no wait).
+ *   gr80211_stream_wait    work enqueued on (ctx, stream) from now on starts after what (other, other_stream) holds now.
+ *   gr80211_marker_record  marks the current end of the stream's queue; returns the marker's number (>= 0).
+ *   gr80211_marker_done    1 if the stream has passed marker `id`, 0 if not; wait != 0: wait for it first.  A context
+ *                          keeps 256 markers: recording one more waits for the marker 256 records back.
+ *   gr80211_host_register  page-locks memory the caller owns (a scheduler's stream buffer) for as long as it is
+ *                          registered, so that copies from it run asynchronously at the rate of the link.
+ */
+int gr80211_copy_h2d_async(gr80211_ctx *ctx, void *d_dst, const void *h_src, size_t bytes, void *stream);
+int gr80211_copy_d2h_async(gr80211_ctx *ctx, void *h_dst, const void *d_src, size_t bytes, void *stream);
+int gr80211_copy_d2d_async(gr80211_ctx *ctx, void *d_dst, const void *d_src, size_t bytes, void *stream); /* no overlap */
+int gr80211_stream_idle(gr80211_ctx *ctx, void *stream);
+int gr80211_stream_wait(gr80211_ctx *ctx, void *stream, gr80211_ctx *other, void *other_stream);
+long long gr80211_marker_record(gr80211_ctx *ctx, void *stream);
+int gr80211_marker_done(gr80211_ctx *ctx, long long id, int wait);
+int gr80211_host_register(gr80211_ctx *ctx, void *p, size_t bytes);
+int gr80211_host_unregister(gr80211_ctx *ctx, void *p);
+
 /*
  * Page-locked host memory: copies to and from it run at the full rate of the link, copies from ordinary memory at
  * a fraction of it.  NULL when the allocation fails.

@@ -695,3 +695,77 @@ def test_submit_and_finish_on_two_contexts_from_one_thread(pkg, oracle):
     for ctx in ctxs:
         ctx.close()
 
+
+
+def test_resume_after_signal_batch_equals_rx_batch(pkg, oracle):
+    """gr80211_signal_batch, then gr80211_rx_resume for a subset of its frames (what a streaming caller does around
+    `signal`'s trigger search): the same PDUs and records as gr80211_rx_batch over those frames, with nothing waited
+    for in between; out of order use is refused; a caller whose copy of the records understates the frames gets a
+    batch that is not run (no PDUs, flag set) instead of one that overruns its buffers."""
+    import torch
+    tx = pkg.txgen
+    rng = np.random.default_rng(44)
+    frames = []
+    for k in range(150):
+        fmt = int(rng.integers(0, 3))
+        mcs = int(rng.integers(0, 8 if fmt < 2 else 9))
+        frames.append(make_noisy(tx, rng, fmt, mcs, 1, int(rng.integers(30, 1400)), 33.0)[0])
+        if k % 9 == 0:
+            noise = (0.1 * (rng.standard_normal(900) + 1j * rng.standard_normal(900))).astype(np.complex64)
+            frames.append(([noise], 300))      # a sync byte on noise: L-SIG fails
+    iq0, _, sync, navail = build_arena(frames)
+    n = len(frames)
+    d0 = torch.from_numpy(iq0).cuda()
+    desc = pkg.RxContext.make_desc(sync, navail)
+    ctx, ref = pkg.RxContext(0), pkg.RxContext(0)
+    try:
+        info_all = ctx.signal_batch(d0, None, desc, n)
+        sel = np.array([i for i in range(n) if info_all["status"][i] != 1 and i % 3 != 1], dtype=np.int32)
+        dsel = desc[sel].copy()
+        dsel["n_avail"] = np.minimum(dsel["n_avail"], 224 + np.maximum(info_all["nsamp"][sel], 0))  # cut to the frame's span
+        m = len(sel)
+        out = torch.zeros((m, 4104), dtype=torch.uint8, device="cuda")
+        out_len = torch.full((m,), -1, dtype=torch.int32, device="cuda")
+        n_pdu = torch.full((m,), -1, dtype=torch.int32, device="cuda")
+        info = torch.zeros(m * pkg.rx.FRAME_INFO_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
+        ctx.rx_resume(d0, None, dsel, sel, info_all, out, out_len, n_pdu, info)
+        with pytest.raises(RuntimeError, match="holds no results"):
+            ctx.rx_resume(d0, None, dsel, sel, info_all, out, out_len, n_pdu)       # the results are spent
+        ctx.sync()
+        assert ctx.lib.gr80211_last_batch_refused(ctx.h) == 0
+        want = ref.rx_batch(d0, None, dsel, m)
+        ref.sync()
+        assert torch.equal(out_len, want["out_len"]) and torch.equal(n_pdu, want["n_pdu"])
+        assert int(n_pdu.sum().item()) >= m - 3
+        wl = want["out_len"].cpu().numpy()
+        go, wo = out.cpu().numpy(), want["out"].cpu().numpy()
+        assert all(bytes(go[i, : wl[i]]) == bytes(wo[i, : wl[i]]) for i in range(m))
+        gi = info.cpu().numpy().view(pkg.rx.FRAME_INFO_DTYPE)
+        wi = want["info"].cpu().numpy().view(pkg.rx.FRAME_INFO_DTYPE)
+        for k in TAGS + ("nCBPS", "nDBPS", "llr_off"):
+            assert np.array_equal(gi[k], wi[k]), k
+        # another batch call between the two steps spends the results as well
+        ctx.signal_batch(d0, None, desc, n)
+        ctx.rx_batch(d0, None, dsel, m)
+        with pytest.raises(RuntimeError, match="holds no results"):
+            ctx.rx_resume(d0, None, dsel, sel, info_all, out, out_len, n_pdu)
+        # a fresh context (small buffers) and records that understate every frame: refused on the device, nothing runs
+        small = pkg.RxContext(0)
+        small.signal_batch(d0, None, desc, n)
+        lie = info_all.copy()
+        lie["total"] = 8
+        lie["trellis"] = 64
+        out_len.fill_(-1)
+        small.rx_resume(d0, None, dsel, sel, lie, out, out_len, n_pdu)
+        small.sync()
+        assert small.lib.gr80211_last_batch_refused(small.h) == 1
+        assert int(out_len.abs().sum().item()) == 0 and int(n_pdu.abs().sum().item()) == 0
+        # and the same context works again with honest records
+        small.signal_batch(d0, None, desc, n)
+        small.rx_resume(d0, None, dsel, sel, info_all, out, out_len, n_pdu)
+        small.sync()
+        assert small.lib.gr80211_last_batch_refused(small.h) == 0 and torch.equal(out_len, want["out_len"])
+        small.close()
+    finally:
+        ctx.close()
+        ref.close()
