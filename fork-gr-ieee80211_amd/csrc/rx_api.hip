@@ -60,6 +60,12 @@ struct gr80211_ctx {
     Buf sel_index;                          // gr80211_rx_resume: which of the frames of the last gr80211_signal_batch go on
     int signal_n = 0;                       // frames of the last gr80211_signal_batch whose records and channels are still held
     bool signal_two = false;                // ... and whether it ran on two antennas
+    uint32_t *pull_flag_h = nullptr;        // pinned: number of the last gr80211_pull_h2d copy that has read all of its source
+    unsigned *pull_ctr_d = nullptr;         // device: workgroups of the running pull copy that have finished
+    long long pull_seq = 0;
+    void *pull_flag_view = nullptr;         // the flag word as the GPU addresses it
+    uintptr_t pull_lo = 0, pull_hi = 0;     // the page-locked range the last pull copy read from ...
+    intptr_t pull_to_dev = 0;               // ... and what turns its host addresses into the GPU's
     static constexpr int N_MARK = 256;
     hipEvent_t mark_ev[N_MARK] = {};        // gr80211_marker_*: created on first use
     long long mark_next = 0;
@@ -420,6 +426,57 @@ void detect_emit(gr80211_ctx *c, hipStream_t s, long long nruns, long long n, gr
 
 }  // namespace
 
+namespace {
+// Page-locked allocations this library has handed out, each with the address the GPU reads it by: a pull copy finds
+// its source here instead of asking the runtime on every call.
+struct HostRange {
+    uintptr_t lo, hi;
+    intptr_t to_dev;  // device view minus host address
+};
+std::mutex g_host_mutex;
+std::vector<HostRange> g_host_ranges;
+
+bool host_range_of(const void *p, size_t bytes, HostRange *out)
+{
+    std::lock_guard<std::mutex> lk(g_host_mutex);
+    const uintptr_t a = (uintptr_t)p;
+    for (const HostRange &r : g_host_ranges)
+        if (a >= r.lo && a + bytes <= r.hi) {
+            *out = r;
+            return true;
+        }
+    return false;
+}
+}  // namespace
+
+namespace {
+// Host-to-device copy as a kernel: the GPU reads page-locked host memory over the link itself.  Costs the host one
+// kernel launch whatever the size (the runtime's own asynchronous copy spends host time in proportion to the bytes).
+// The workgroup that finishes last writes the copy's number to a page-locked word, which is how the host learns,
+// without a call into the runtime, that the source may be overwritten.
+typedef unsigned int pull_u4 __attribute__((ext_vector_type(4)));
+typedef unsigned int pull_u2 __attribute__((ext_vector_type(2)));
+template <class V>
+__global__ __launch_bounds__(256) void k_pull(V *__restrict__ dst, const V *__restrict__ src, size_t n_wide,
+                                              unsigned char *__restrict__ dst_tail, const unsigned char *__restrict__ src_tail,
+                                              int n_tail, unsigned *__restrict__ finished, uint32_t *__restrict__ flag, uint32_t number)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_wide; i += stride)
+        dst[i] = __builtin_nontemporal_load(src + i);
+    if (blockIdx.x == 0 && (int)threadIdx.x < n_tail) dst_tail[threadIdx.x] = src_tail[threadIdx.x];
+    // every load of this workgroup has returned once its threads are here (each store above needed its load's data)
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned before = __hip_atomic_fetch_add(finished, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (before == gridDim.x - 1) {
+            __hip_atomic_store(finished, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // for the next copy of this stream
+            __hip_atomic_store(flag, number, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+}  // namespace
+
 extern "C" {
 
 const char *gr80211_version(void) { return "gr80211_rx 0.1 (gfx950)"; }
@@ -490,6 +547,8 @@ void gr80211_destroy(gr80211_ctx *c)
     if (c->totals_h) (void)hipHostFree(c->totals_h);
     if (c->det_totals_h) (void)hipHostFree(c->det_totals_h);
     if (c->na_desc_h) (void)hipHostFree(c->na_desc_h);
+    if (c->pull_flag_h) (void)hipHostFree(c->pull_flag_h);
+    if (c->pull_ctr_d) (void)hipFree(c->pull_ctr_d);
     for (auto &e : c->ev)
         if (e) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -955,6 +1014,86 @@ int gr80211_copy_h2d_async(gr80211_ctx *c, void *d_dst, const void *h_src, size_
     return GR80211_OK;
 }
 
+long long gr80211_pull_h2d(gr80211_ctx *c, void *d_dst, const void *h_src, size_t bytes, void *stream)
+{
+    if (!c) return GR80211_ERR_ARG;
+    if (!bytes || !d_dst || !h_src) return fail(c, GR80211_ERR_ARG, "gr80211_pull_h2d: bad argument");
+    if (hipSetDevice(c->device) != hipSuccess) return fail(c, GR80211_ERR_HIP, "hipSetDevice");
+    if (!c->pull_flag_h) {
+        if (hipHostMalloc((void **)&c->pull_flag_h, 64) != hipSuccess || hipMalloc((void **)&c->pull_ctr_d, 64) != hipSuccess ||
+            hipMemset(c->pull_ctr_d, 0, 64) != hipSuccess)
+            return fail(c, GR80211_ERR_NOMEM, "gr80211_pull_h2d: set-up failed");
+        *c->pull_flag_h = 0;
+        if (hipHostGetDevicePointer(&c->pull_flag_view, c->pull_flag_h, 0) != hipSuccess) return fail(c, GR80211_ERR_HIP, "hipHostGetDevicePointer");
+    }
+    // the last range that matched is tried first (a stream buffer is used call after call)
+    void *dev_view = nullptr;
+    const uintptr_t a = (uintptr_t)h_src;
+    if (!(a >= c->pull_lo && a + bytes <= c->pull_hi)) {
+        HostRange r{0, 0, 0};
+        (void)host_range_of(h_src, bytes, &r);
+        c->pull_lo = r.lo, c->pull_hi = r.hi, c->pull_to_dev = r.to_dev;
+    }
+    if (c->pull_hi) {
+        dev_view = (void *)(a + c->pull_to_dev);
+    } else {
+        const hipError_t e = hipHostGetDevicePointer(&dev_view, const_cast<void *>(h_src), 0);
+        if (e != hipSuccess || !dev_view) {
+            (void)hipGetLastError();
+            return fail(c, GR80211_ERR_ARG, "gr80211_pull_h2d: the source is not page-locked host memory the GPU can read", e);
+        }
+    }
+    void *flag_view = c->pull_flag_view;
+    // the widest element both addresses are aligned to: 16 bytes, 8 (a stream of complex samples cut at an odd item), 4 or 1
+    const uintptr_t both = (uintptr_t)dev_view | (uintptr_t)d_dst;
+    const int width = !(both & 15) ? 16 : !(both & 7) ? 8 : !(both & 3) ? 4 : 1;
+    const size_t n_wide = bytes / width;
+    const int n_tail = (int)(bytes - n_wide * width);
+    size_t blocks = (n_wide + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    const long long number = ++c->pull_seq;
+    unsigned char *dt = (unsigned char *)d_dst + n_wide * width;
+    const unsigned char *st = (const unsigned char *)dev_view + n_wide * width;
+    const dim3 grid((unsigned)blocks), wg(256);
+    hipStream_t on = pick(c, stream);
+    uint32_t *fl = (uint32_t *)flag_view;
+    if (width == 16)
+        hipLaunchKernelGGL(k_pull<pull_u4>, grid, wg, 0, on, (pull_u4 *)d_dst, (const pull_u4 *)dev_view, n_wide, dt, st, n_tail,
+                           c->pull_ctr_d, fl, (uint32_t)number);
+    else if (width == 8)
+        hipLaunchKernelGGL(k_pull<pull_u2>, grid, wg, 0, on, (pull_u2 *)d_dst, (const pull_u2 *)dev_view, n_wide, dt, st, n_tail,
+                           c->pull_ctr_d, fl, (uint32_t)number);
+    else if (width == 4)
+        hipLaunchKernelGGL(k_pull<unsigned>, grid, wg, 0, on, (unsigned *)d_dst, (const unsigned *)dev_view, n_wide, dt, st, n_tail,
+                           c->pull_ctr_d, fl, (uint32_t)number);
+    else
+        hipLaunchKernelGGL(k_pull<unsigned char>, grid, wg, 0, on, (unsigned char *)d_dst, (const unsigned char *)dev_view, n_wide,
+                           dt, st, n_tail, c->pull_ctr_d, fl, (uint32_t)number);
+    if (hipGetLastError() != hipSuccess) return fail(c, GR80211_ERR_HIP, "gr80211_pull_h2d: launch failed");
+    return number;
+}
+
+int gr80211_pull_done(gr80211_ctx *c, long long number, int wait)
+{
+    if (!c || number < 1 || number > c->pull_seq || !c->pull_flag_h) return GR80211_ERR_ARG;
+    volatile uint32_t *f = c->pull_flag_h;
+    // the numbers of one stream's copies arrive in order; (int32_t) difference: the 32-bit word may wrap
+    if ((int32_t)(*f - (uint32_t)number) >= 0) return 1;
+    if (!wait) return 0;
+    for (long spins = 0; (int32_t)(*f - (uint32_t)number) < 0; spins++) {
+        if (spins > 2000 && (spins & 1023) == 0) {
+            // a copy that takes this long may be behind work that has failed: ask the runtime
+            const hipError_t e = hipStreamQuery(c->stream);
+            if (e != hipSuccess && e != hipErrorNotReady) return fail(c, GR80211_ERR_HIP, "gr80211_pull_done", e);
+            if (e == hipSuccess && (int32_t)(*f - (uint32_t)number) < 0 && spins > 200000000)
+                return fail(c, GR80211_ERR_HIP, "gr80211_pull_done: the copy's number never arrived");
+        }
+        __builtin_ia32_pause();
+    }
+    return 1;
+}
+
 int gr80211_copy_d2h_async(gr80211_ctx *c, void *h_dst, const void *d_src, size_t bytes, void *stream)
 {
     if (!c) return GR80211_ERR_ARG;
@@ -1026,7 +1165,11 @@ int gr80211_host_register(gr80211_ctx *c, void *p, size_t bytes)
 {
     if (!c || !p || !bytes) return GR80211_ERR_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, hipHostRegister(p, bytes, hipHostRegisterDefault));
+    const hipError_t e = hipHostRegister(p, bytes, hipHostRegisterDefault);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();  // a system that cannot lock user pages says so here; the error must not stick to later calls
+        return fail(c, GR80211_ERR_HIP, "hipHostRegister", e);
+    }
     return GR80211_OK;
 }
 
@@ -1101,12 +1244,28 @@ void *gr80211_host_alloc(gr80211_ctx *c, size_t bytes)
     if (hipSetDevice(c->device) != hipSuccess) return nullptr;
     void *p = nullptr;
     if (hipHostMalloc(&p, bytes ? bytes : 1) != hipSuccess) return nullptr;
+    void *view = nullptr;
+    if (hipHostGetDevicePointer(&view, p, 0) == hipSuccess && view) {
+        std::lock_guard<std::mutex> lk(g_host_mutex);
+        g_host_ranges.push_back({(uintptr_t)p, (uintptr_t)p + (bytes ? bytes : 1), (intptr_t)((uintptr_t)view - (uintptr_t)p)});
+    } else {
+        (void)hipGetLastError();
+    }
     return p;
 }
 
 void gr80211_host_free(gr80211_ctx *c, void *p)
 {
-    if (c && p) (void)hipHostFree(p);
+    if (!c || !p) return;
+    {
+        std::lock_guard<std::mutex> lk(g_host_mutex);
+        for (size_t i = 0; i < g_host_ranges.size(); i++)
+            if (g_host_ranges[i].lo == (uintptr_t)p) {
+                g_host_ranges.erase(g_host_ranges.begin() + (long)i);
+                break;
+            }
+    }
+    (void)hipHostFree(p);
 }
 
 int gr80211_copy_h2d(gr80211_ctx *c, void *d_dst, const void *h_src, size_t bytes, void *stream)

@@ -2,13 +2,22 @@
 #include "gr80211_blocks.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 namespace gr80211 {
 namespace host {
 
 namespace {
+
+struct stopwatch {  // adds the time it lives to a counter
+    double &acc;
+    std::chrono::steady_clock::time_point t0;
+    explicit stopwatch(double &a) : acc(a), t0(std::chrono::steady_clock::now()) {}
+    ~stopwatch() { acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+};
 
 const int LSIG_SPAN = 224;       // samples from the trigger to the end of L-SIG (lib/signal_impl.cc:110,154)
 const int F_VHT_CHAN = 20;       // format byte of the sounding channel message (lib/cloud80211phy.h:40)
@@ -37,6 +46,12 @@ const tag_t *tag_find(const std::vector<tag_t> &tags, const char *key)
 // Index of the first non-zero byte of s[i, n), or n: a sync stream is almost all zeros, so eight bytes go at a time.
 int next_set(const uint8_t *s, int i, int n)
 {
+    while (i + 64 <= n) {  // a cache line at a time while nothing is set
+        uint64_t w[8];
+        memcpy(w, s + i, 64);
+        if (w[0] | w[1] | w[2] | w[3] | w[4] | w[5] | w[6] | w[7]) break;
+        i += 64;
+    }
     while (i + 8 <= n) {
         uint64_t w;
         memcpy(&w, s + i, 8);
@@ -73,6 +88,19 @@ void block::get_tags_in_range(std::vector<tag_t> &v, int port, uint64_t start, u
     for (; it != tv.end() && it->offset < end; ++it) v.push_back(*it);
 }
 
+bool block::tag_values_at(int port, uint64_t offset, const char *const *keys, double *out, int n_keys) const
+{
+    const std::deque<tag_t> &tv = d_tags[port];
+    auto it = std::lower_bound(tv.begin(), tv.end(), offset, [](const tag_t &t, uint64_t o) { return t.offset < o; });
+    bool any = false;
+    for (; it != tv.end() && it->offset == offset; ++it) {
+        any = true;
+        for (int k = 0; k < n_keys; k++)
+            if (it->key == keys[k]) out[k] = it->value;
+    }
+    return any;
+}
+
 std::vector<tag_t> block::take_output_tags(int port)
 {
     std::vector<tag_t> t;
@@ -102,10 +130,9 @@ uint64_t block::publish_slots(const uint8_t *out, const int32_t *len, int n, int
             const int L = p[at + 1] | (p[at + 2] << 8);
             const int rec = L + (p[at] == F_VHT_CHAN ? 3 : 4);  // a channel message has no trailing mcs byte
             if (at + rec > len[i] || at + rec > stride) break;
-            pdu_t m;
-            m.blob.assign(p + at, p + at + rec);
-            m.len = rec;
-            message_port_pub("out", m);
+            d_msg.blob.assign(p + at, p + at + rec);
+            d_msg.len = rec;
+            message_port_pub("out", d_msg);
             n_pub++;
             at += rec;
         }
@@ -116,6 +143,91 @@ uint64_t block::publish_slots(const uint8_t *out, const int32_t *len, int n, int
 void block::message_port_pub(const std::string &port, const pdu_t &m)
 {
     if (d_handler) d_handler(port, m);
+}
+
+void *block::alloc_input(size_t bytes)
+{
+    gr80211_ctx *c = pin_context();
+    if (!c || !bytes) return nullptr;
+    void *p = gr80211_host_alloc(c, bytes);
+    if (!p) return nullptr;
+    d_pinned.emplace_back(static_cast<const char *>(p), bytes);
+    d_owned.push_back(p);
+    return p;
+}
+
+void block::free_input(void *p)
+{
+    gr80211_ctx *c = pin_context();
+    for (size_t i = 0; i < d_owned.size(); i++)
+        if (d_owned[i] == p) {
+            d_owned.erase(d_owned.begin() + (long)i);
+            for (size_t k = 0; k < d_pinned.size(); k++)
+                if (d_pinned[k].first == p) {
+                    d_pinned.erase(d_pinned.begin() + (long)k);
+                    break;
+                }
+            if (c) gr80211_host_free(c, p);
+            return;
+        }
+}
+
+bool block::pin_input(const void *p, size_t bytes)
+{
+    gr80211_ctx *c = pin_context();
+    if (!c || !p || !bytes) return false;
+    if (is_pinned(p, bytes)) return true;
+    if (gr80211_host_register(c, const_cast<void *>(p), bytes) != GR80211_OK) return false;
+    d_pinned.emplace_back(static_cast<const char *>(p), bytes);
+    d_registered.push_back(static_cast<const char *>(p));
+    return true;
+}
+
+bool block::is_pinned(const void *p, size_t bytes) const
+{
+    const char *q = static_cast<const char *>(p);
+    for (const auto &r : d_pinned)
+        if (q >= r.first && q + bytes <= r.first + r.second) return true;
+    return false;
+}
+
+// Called by the destructor of every block that has a context, while that context still exists.
+void block::unpin_all()
+{
+    gr80211_ctx *c = pin_context();
+    if (c) {
+        for (const char *p : d_registered) gr80211_host_unregister(c, const_cast<char *>(p));
+        for (void *p : d_owned) gr80211_host_free(c, p);
+    }
+    d_registered.clear();
+    d_owned.clear();
+    d_pinned.clear();
+}
+
+uint64_t upload_log::settled(uint64_t from)
+{
+    uint64_t upto = from;
+    while (!d_q.empty()) {
+        const entry &e = d_q.front();
+        if (e.g) {
+            // nothing free yet and a copy on its way: wait for it, so that every call consumes something
+            const int wait = upto == from ? 1 : 0;
+            const int done = e.pull ? gr80211_pull_done(e.g->ctx(), e.id, wait) : gr80211_marker_done(e.g->ctx(), e.id, wait);
+            if (done != 1) break;
+        }
+        upto = std::max(upto, e.upto);
+        d_q.pop_front();
+    }
+    return upto;
+}
+
+bool upload_log::drain()
+{
+    bool ok = true;
+    for (const entry &e : d_q)
+        if (e.g && (e.pull ? gr80211_pull_done(e.g->ctx(), e.id, 1) : gr80211_marker_done(e.g->ctx(), e.id, 1)) != 1) ok = false;
+    d_q.clear();
+    return ok;
 }
 
 // ------------------------------------------------------------------------------------ gpu_session
@@ -261,7 +373,7 @@ decode::decode(bool ifdebug, int batch_frames, int device)
     if (!d_gpu.ok()) d_err = "gr80211_create failed";
 }
 
-decode::~decode() {}
+decode::~decode() { unpin_all(); }
 
 void decode::forecast(int noutput_items, gr_vector_int &ninput_items_required)
 {
@@ -428,16 +540,77 @@ bool decode::run_batch()
 }
 
 // ------------------------------------------------------------------------------------ rx
+namespace {
+// A frame's longest span: 224 samples to the end of L-SIG, then what the longest L-SIG length announces at the
+// lowest rate (lib/signal_impl.cc:126-131): a sync byte further than this from the end of a round has its whole frame
+// inside the round.
+const size_t MAX_SPAN = 224 + 80 * ((4095 * 8 + 22 + 23) / 24);
+}  // namespace
+
 rx::sptr rx::make(int n_rx, int batch_frames, int device) { return sptr(new rx(n_rx, batch_frames, device)); }
 
 rx::rx(int n_rx, int batch_frames, int device, int n_out)
     : block(n_rx == 2 ? 3 : 2, n_out), d_nrx(n_rx == 2 ? 2 : 1), d_batch(batch_frames < 1 ? 1 : batch_frames), d_gpu(device),
-      d_hold0(d_gpu, sizeof(gr_complex)), d_hold1(d_gpu, sizeof(gr_complex)), d_maxHold((size_t)1 << 22)
+      d_gpu2(device), d_maxHold((size_t)1 << 24)
 {
-    if (!d_gpu.ok()) d_err = "gr80211_create failed";
+    if (!d_gpu.ok() || !d_gpu2.ok()) {
+        d_err = "gr80211_create failed";
+        return;
+    }
+    for (round &r : d_round) {
+        r.gpu.reset(new gpu_session(device));
+        if (!r.gpu->ok()) {
+            d_err = "gr80211_create failed";
+            return;
+        }
+    }
+    d_fill = &d_round[0];
+    d_fill->state = round::FILL;
+    if (const char *e = getenv("GR80211_RX_MAX_HOLD")) set_max_hold((size_t)atoll(e));  // experiments
+    d_profile = getenv("GR80211_BLOCK_PROFILE") != nullptr;
+    if (const char *e = getenv("GR80211_RX_SPLIT")) d_firstSplit = atoi(e);  // experiments
+    // the arenas of the first two rounds exist before the stream starts (making one takes milliseconds); the others
+    // follow when a stream is fast enough to need them
+    for (int k = 0; k < 2; k++) {
+        round &r = d_round[k];
+        const size_t nf = (size_t)std::min(d_batch, 8192), np = nf + nf / 8;
+        if (!reserve(r, 1) || !r.gpu->buffer(2, np * sizeof(gr80211_frame_info)) || !r.gpu->staging(2, np * sizeof(gr80211_frame_info)) ||
+            !r.gpu->buffer(3, nf * OUT_STRIDE) || !r.gpu->buffer(4, nf * 4) || !r.gpu->buffer(5, nf * 4) ||
+            !r.gpu->staging(0, nf * OUT_STRIDE) || !r.gpu->staging(1, nf * 4)) {
+            d_err = "device memory for the held samples exhausted";
+            return;
+        }
+    }
 }
 
-rx::~rx() {}
+rx::~rx()
+{
+    if (getenv("GR80211_BLOCK_PROFILE"))
+        fprintf(stderr, "rx block: %llu calls, %llu rounds; host seconds: scan %.4f upload %.4f settle %.4f advance %.4f "
+                        "(of which cut %.4f publish %.4f)\n", (unsigned long long)d_nCalls, (unsigned long long)d_nRounds,
+                d_tScan, d_tUpload, d_tSettle, d_tAdvance, d_tCut, d_tPublish);
+    // nothing of this block may still be on its way when its buffers go
+    d_up.drain();
+    if (d_gpu.ok()) d_gpu.sync();
+    if (d_gpu2.ok()) d_gpu2.sync();
+    for (round &r : d_round) {
+        if (!r.gpu || !r.gpu->ok()) continue;
+        r.gpu->sync();
+        for (char *&q : r.iq)
+            if (q) gr80211_dev_free(r.gpu->ctx(), q);
+    }
+    unpin_all();
+}
+
+void rx::set_ampdu_strict(bool on)
+{
+    d_strict = on;
+    d_gpu.set_ampdu_strict(on);
+    for (round &r : d_round)
+        if (r.gpu) r.gpu->set_ampdu_strict(on);
+}
+
+void rx::set_max_hold(size_t items) { d_maxHold = std::max(items, 4 * MAX_SPAN); }
 
 void rx::forecast(int noutput_items, gr_vector_int &ninput_items_required)
 {
@@ -451,203 +624,398 @@ int rx::general_work(int, gr_vector_int &ninput_items, gr_vector_const_void_star
     return 0;
 }
 
-// The input half of general_work: triggers and samples of this window go to the pending lists, a round of
-// processing runs when enough has gathered.
-int rx::take_input(gr_vector_int &ninput_items, gr_vector_const_void_star &input_items)
+bool rx::reserve(round &r, size_t items)
 {
-    const uint8_t *sync = static_cast<const uint8_t *>(input_items[0]);
-    int n = std::min(ninput_items[0], ninput_items[1]);
-    if (d_nrx == 2) n = std::min(n, ninput_items[2]);
-    std::vector<tag_t> tags;
-    for (int i = next_set(sync, 0, n); i < n; i = next_set(sync, i + 1, n)) {
-        const uint64_t at = nitems_read(0) + (uint64_t)i;
-        get_tags_in_range(tags, 0, at, at + 1);
-        if (tags.empty()) continue;  // "input sync with no tag" (lib/signal_impl.cc:96-100): not a trigger
-        trigger t;
-        t.pos = at;
-        t.rad = (float)tag_value(tags, "rad", 0.0);
-        t.snr = (float)tag_value(tags, "snr", 0.0);
-        t.rssi = (float)tag_value(tags, "rssi", 0.0);
-        t.probed = false;
-        t.status = 0;
-        t.nsamp = 0;
-        t.mcs = 0;
-        t.len = 0;
-        d_trig.push_back(t);
-        d_nTrig++;
-    }
-    // samples are only held from the first pending trigger on
-    int from = 0;
-    if (d_hold0.empty()) {
-        if (d_trig.empty()) {
-            from = n;
-        } else {
-            const uint64_t first = std::max(d_trig[0].pos, nitems_read(0));
-            from = (int)(first - nitems_read(0));
-        }
-        d_base = nitems_read(0) + (uint64_t)from;
-    }
+    if (items <= r.cap) return true;
+    gr80211_ctx *c = r.gpu->ctx();
+    // an arena is made for a whole round at once (what a round may hold, the longest carried-over stretch and a
+    // window on top): growing it later means a copy and a wait
+    size_t cap = std::max<size_t>(std::max<size_t>(2 * r.cap, items), std::min<size_t>(d_maxHold, (size_t)1 << 25) + 2 * MAX_SPAN + ((size_t)1 << 20));
     for (int a = 0; a < d_nrx; a++) {
-        const gr_complex *s = static_cast<const gr_complex *>(input_items[1 + a]);
-        if (!hold(a).append(s + from, (size_t)(n - from))) {
-            d_err = "upload of the samples failed: " + d_gpu.error();
-            return -1;
+        char *q = static_cast<char *>(gr80211_dev_alloc(c, (cap + 64) * sizeof(gr_complex)));
+        if (!q) return false;
+        // what the arena holds moves over once the copies that are filling it have run
+        if (r.n && !(d_gpu.sync() && d_gpu2.sync())) return false;
+        if (r.n && gr80211_copy_d2d_async(c, q, r.iq[a], r.n * sizeof(gr_complex), nullptr) != GR80211_OK) return false;
+        if (r.iq[a]) {
+            if (!r.gpu->sync()) return false;
+            gr80211_dev_free(c, r.iq[a]);
         }
+        r.iq[a] = q;
     }
-    if ((int)d_trig.size() >= d_batch || d_hold0.size() >= d_maxHold) process(false);
-    return n;
-}
-
-bool rx::flush() { return process(true); }
-
-// One round: learn the span of every buffered trigger (L-SIG), replay the trigger/copy state machine of
-// `signal` over them in stream order, decode the frames whose samples are complete, release what is done.
-bool rx::process(bool final)
-{
-    const uint64_t held_end = d_base + d_hold0.size();
-    // triggers at or behind the search position can never start a frame
-    {
-        size_t k = 0;
-        while (k < d_trig.size() && d_trig[k].pos < d_cursor) k++;
-        if (k) d_trig.erase(d_trig.begin(), d_trig.begin() + (long)k);
-    }
-    if (d_trig.empty()) {
-        // nothing pending: everything held so far can go
-        d_cursor = std::max(d_cursor, held_end);
-        for (int a = 0; a < d_nrx; a++) hold(a).clear();
-        d_base = held_end;
-        return true;
-    }
-    if (!d_gpu.ok()) return false;
-    gr80211_ctx *c = d_gpu.ctx();
-    const size_t nheld = d_hold0.size();
-    // the samples are on the device already: every window was uploaded when it arrived
-    const void *diq0 = d_hold0.data();
-    const void *diq1 = d_nrx == 2 ? d_hold1.data() : nullptr;
-
-    // ---- 1. spans: L-SIG of every trigger that has its 224 samples (lib/signal_impl.cc:108-131)
-    std::vector<gr80211_frame_desc> pd;
-    std::vector<size_t> pidx;
-    for (size_t j = 0; j < d_trig.size(); j++) {
-        trigger &t = d_trig[j];
-        if (t.probed) continue;
-        const uint64_t rel = t.pos - d_base;
-        if (rel + LSIG_SPAN > nheld) continue;  // `signal` waits for 224 samples too
-        gr80211_frame_desc d;
-        memset(&d, 0, sizeof(d));
-        d.sync_off = rel;
-        d.n_avail = (uint32_t)std::min<uint64_t>(nheld - rel, 0xffffffffu);
-        d.rad = t.rad;
-        d.snr = t.snr;
-        d.rssi = t.rssi;
-        d.mu_pos = (uint32_t)d_muPos;
-        pd.push_back(d);
-        pidx.push_back(j);
-    }
-    if (!pd.empty()) {
-        const int np = (int)pd.size();
-        gr80211_frame_info *dinfo =
-            static_cast<gr80211_frame_info *>(d_gpu.buffer(2, (size_t)np * sizeof(gr80211_frame_info)));
-        std::vector<gr80211_frame_info> info(np);
-        if (!dinfo || gr80211_signal_batch(c, diq0, diq1, nheld, pd.data(), np, 0, dinfo, nullptr) != GR80211_OK ||
-            gr80211_copy_d2h(c, info.data(), dinfo, (size_t)np * sizeof(gr80211_frame_info), nullptr) != GR80211_OK) {
-            d_err = d_gpu.error();
-            return false;
-        }
-        for (int k = 0; k < np; k++) {
-            trigger &t = d_trig[pidx[k]];
-            t.probed = true;
-            t.status = info[k].status;
-            t.nsamp = info[k].nsamp;
-            t.mcs = info[k].lsig_mcs;
-            t.len = info[k].lsig_len;
-        }
-    }
-
-    // ---- 2. the trigger search in stream order (lib/signal_impl.cc:75-106,153-160,164-202)
-    std::vector<gr80211_frame_desc> fd;
-    std::vector<frame_ref> fr;
-    size_t done = 0;  // triggers settled in this round
-    for (size_t j = 0; j < d_trig.size(); j++) {
-        const trigger &t = d_trig[j];
-        if (t.pos < d_cursor) {  // inside the previous frame's span: `signal` never looks at it
-            done = j + 1;
-            continue;
-        }
-        if (!t.probed) {
-            if (final) done = j + 1;  // fewer than 224 samples before the end of the stream
-            break;
-        }
-        if (t.status == GR80211_ST_DROP_LSIG) {
-            d_cursor = t.pos + LSIG_FAIL_SKIP;
-            done = j + 1;
-            continue;
-        }
-        const uint64_t span = (uint64_t)LSIG_SPAN + (uint64_t)(t.nsamp > 0 ? t.nsamp : 0);
-        if (t.pos + span > held_end && !final) break;  // its samples are still arriving
-        gr80211_frame_desc d;
-        memset(&d, 0, sizeof(d));
-        d.sync_off = t.pos - d_base;
-        d.n_avail = (uint32_t)std::min<uint64_t>(span, held_end - t.pos);
-        d.rad = t.rad;
-        d.snr = t.snr;
-        d.rssi = t.rssi;
-        d.mu_pos = (uint32_t)d_muPos;
-        fd.push_back(d);
-        frame_ref r;
-        r.pos = t.pos;
-        r.mcs = t.mcs;
-        r.len = t.len;
-        r.nsamp = t.nsamp > 0 ? t.nsamp : 0;
-        r.rad = t.rad;
-        r.snr = t.snr;
-        r.rssi = t.rssi;
-        fr.push_back(r);
-        d_cursor = t.pos + span;
-        done = j + 1;
-    }
-
-    // ---- 3. the complete frames, in stream order
-    if (!fd.empty() && !handle_frames(diq0, diq1, nheld, fd, fr)) return false;
-
-    // ---- 4. release settled triggers and the samples nothing pending can need
-    d_trig.erase(d_trig.begin(), d_trig.begin() + (long)done);
-    uint64_t keep_from = held_end;
-    if (!d_trig.empty() && !final) keep_from = std::min(keep_from, std::max(d_trig[0].pos, d_base));
-    if (final) d_trig.clear();
-    const size_t drop = (size_t)(keep_from - d_base);
-    for (int a = 0; a < d_nrx; a++)
-        if (!hold(a).release_front(drop)) {
-            d_err = "release of the held samples failed: " + d_gpu.error();
-            return false;
-        }
-    d_base = keep_from;
+    r.cap = cap;
     return true;
 }
 
-// rx: decode the frames and publish their PDUs
-bool rx::handle_frames(const void *diq0, const void *diq1, size_t nheld, std::vector<gr80211_frame_desc> &fd,
-                       const std::vector<frame_ref> &)
+rx::round *rx::free_round()
 {
-    gr80211_ctx *c = d_gpu.ctx();
-    const int nf = (int)fd.size();
-    uint8_t *dout = static_cast<uint8_t *>(d_gpu.buffer(3, (size_t)nf * OUT_STRIDE));
-    int32_t *dlen = static_cast<int32_t *>(d_gpu.buffer(4, (size_t)nf * 4));
-    int32_t *dnp = static_cast<int32_t *>(d_gpu.buffer(5, (size_t)nf * 4));
-    uint8_t *out = static_cast<uint8_t *>(d_gpu.staging(0, (size_t)nf * OUT_STRIDE));
-    int32_t *len = static_cast<int32_t *>(d_gpu.staging(1, (size_t)nf * 4));
+    for (;;) {
+        for (round &r : d_round)
+            if (r.state == round::FREE) return &r;
+        if (d_flight.empty() || !advance(true, false)) return nullptr;  // the oldest round in flight gives its place
+    }
+}
+
+// The input half of general_work: the new part of the window goes to the round being filled (sync bytes to its list,
+// samples to its arenas), rounds in flight move on as far as they can without waiting, and the items whose copies have
+// run are consumed.
+int rx::take_input(gr_vector_int &ninput_items, gr_vector_const_void_star &input_items)
+{
+    if (!d_err.empty()) return -1;
+    const uint8_t *sync = static_cast<const uint8_t *>(input_items[0]);
+    int n = std::min(ninput_items[0], ninput_items[1]);
+    if (d_nrx == 2) n = std::min(n, ninput_items[2]);
+    const uint64_t r0 = nitems_read(0);
+    if (d_up.enqueued() < r0) d_up.set_enqueued(r0);
+    d_nCalls++;
+    if ((d_nCalls & 3) == 0 && !d_flight.empty()) {  // asking the runtime about the rounds in flight costs a few us: not every call
+        stopwatch sw(d_tAdvance);
+        if (!advance(false, false)) return -1;
+    }
+    // items [lo, n) of the window are new; the ones before were taken by an earlier call and wait for their copies
+    const int lo = (int)std::min<uint64_t>(d_up.enqueued() - r0, (uint64_t)n);
+    if (lo < n) {
+        round &f = *d_fill;
+        std::vector<tag_t> tags;
+        const size_t trig_before = f.trig.size();
+        stopwatch *sw_scan = new stopwatch(d_tScan);
+        static const char *const keys[3] = {"rad", "snr", "rssi"};
+        for (int i = next_set(sync, lo, n); i < n; i = next_set(sync, i + 1, n)) {
+            const uint64_t at = r0 + (uint64_t)i;
+            double v[3] = {0.0, 0.0, 0.0};
+            if (!tag_values_at(0, at, keys, v, 3)) continue;  // "input sync with no tag" (lib/signal_impl.cc:96-100): not a trigger
+            trigger t;
+            t.pos = at;
+            t.rad = (float)v[0];
+            t.snr = (float)v[1];
+            t.rssi = (float)v[2];
+            f.trig.push_back(t);
+            d_nTrig++;
+        }
+        f.n_new += f.trig.size() - trig_before;
+        delete sw_scan;
+        stopwatch sw_up(d_tUpload);
+        // samples are only held from the first pending sync byte on
+        int from = lo;
+        if (f.n == 0) {
+            if (f.trig.empty()) {
+                from = n;
+            } else {
+                const uint64_t first = std::max(f.trig[0].pos, r0 + (uint64_t)lo);
+                from = (int)(first - r0);
+            }
+            f.base = r0 + (uint64_t)from;
+        }
+        if (from < n) {
+            const size_t cnt = (size_t)(n - from);
+            if (!reserve(f, f.n + cnt)) {
+                d_err = "device memory for the held samples exhausted";
+                return -1;
+            }
+            if (from > lo) d_up.add(nullptr, 0, r0 + (uint64_t)from);  // items passed over need no copy
+            bool pinned = true;
+            for (int a = 0; a < d_nrx; a++)
+                pinned = pinned && is_pinned(static_cast<const gr_complex *>(input_items[1 + a]) + from, cnt * sizeof(gr_complex));
+            // Page-locked windows travel in pieces, each with its own completion: this call consumes the first piece's
+            // items and leaves the others on their way, later calls add what they are newly offered as one more piece
+            // and consume what has arrived, so that copies are queued ahead of the link while the host works.  Only a
+            // window that finds nothing on its way is cut up: then the lag has to be built.
+            size_t pieces = 1;
+            if (pinned && d_up.empty()) pieces = d_firstSplit ? (size_t)d_firstSplit : cnt >= ((size_t)1 << 19) ? 8 : cnt >= ((size_t)1 << 17) ? 4 : cnt >= 32768 ? 2 : 1;
+            const size_t half = (cnt / pieces) & ~(size_t)1;
+            // small pieces go by the kernel that reads host memory itself (a launch, nothing else); from a megabyte on
+            // the runtime's copy engines are faster and do not share the compute units with the decoders
+            static const char *mode = getenv("GR80211_UPLOAD");  // "dma" / "pull": one way for every size (experiments)
+            for (size_t at = 0, k = 0; at < cnt; k++) {
+                const size_t len = k + 1 < pieces ? half : cnt - at;
+                const bool use_dma = mode ? mode[0] == 'd' : len * sizeof(gr_complex) >= ((size_t)1 << 20);
+                long long id = 0;
+                // asynchronous copies alternate between the block's two upload streams
+                gpu_session *via = !pinned ? f.gpu.get() : (d_nPiece++ & 1) ? &d_gpu2 : &d_gpu;
+                gr80211_ctx *c = via->ctx();
+                for (int a = 0; a < d_nrx; a++) {
+                    const gr_complex *src = static_cast<const gr_complex *>(input_items[1 + a]) + from + at;
+                    char *dst = f.iq[a] + (f.n + at) * sizeof(gr_complex);
+                    const long long rc = !pinned ? gr80211_copy_h2d(c, dst, src, len * sizeof(gr_complex), nullptr)
+                                         : use_dma ? gr80211_copy_h2d_async(c, dst, src, len * sizeof(gr_complex), nullptr)
+                                                   : gr80211_pull_h2d(c, dst, src, len * sizeof(gr_complex), nullptr);
+                    if (rc < 0) {
+                        d_err = "upload of the samples failed: " + f.gpu->error();
+                        return -1;
+                    }
+                    id = rc;  // the last antenna's copy is the last to finish
+                }
+                at += len;
+                if (pinned && use_dma) {
+                    id = gr80211_marker_record(c, nullptr);
+                    if (id < 0) {
+                        d_err = "marker: " + f.gpu->error();
+                        return -1;
+                    }
+                }
+                if (pinned)
+                    d_up.add(via, id, r0 + (uint64_t)from + at, !use_dma);
+                else
+                    d_up.add(nullptr, 0, r0 + (uint64_t)from + at);  // an ordinary copy has run when it returns
+            }
+            f.n += cnt;
+        } else {
+            d_up.add(nullptr, 0, r0 + (uint64_t)n);
+        }
+        d_up.set_enqueued(r0 + (uint64_t)n);
+        // a round is cut when enough sync bytes are pending (the frame a round carried over counts once its samples
+        // have come in), or when it holds as many samples as it may
+        const uint64_t end = f.base + f.n;
+        const bool enough = f.trig.size() >= (size_t)d_batch && (f.n_new > 0 || (d_wantEnd && end >= d_wantEnd));
+        if (f.n > 0 && (enough || f.n >= d_maxHold)) {
+            stopwatch sw_cut(d_tCut);
+            if (!cut(false)) return -1;
+        }
+    }
+    stopwatch sw_settle(d_tSettle);
+    const uint64_t upto = d_up.settled(r0);
+    return (int)(upto - r0);
+}
+
+// The round being filled goes on its way (probe of every sync byte's L-SIG, then the copy of the records to the
+// host); the next round starts with the samples of the sync bytes whose frames may not have arrived in full.
+bool rx::cut(bool final)
+{
+    round &r = *d_fill;
+    gr80211_ctx *c = r.gpu->ctx();
+    const uint64_t end = r.base + r.n;
+    r.final = final;
+    // whatever the round's stream does from here on comes after the uploads, which went by the block's two streams
+    if (d_nPiece && (gr80211_stream_wait(c, nullptr, d_gpu.ctx(), nullptr) != GR80211_OK ||
+                     gr80211_stream_wait(c, nullptr, d_gpu2.ctx(), nullptr) != GR80211_OK)) {
+        d_err = r.gpu->error();
+        return false;
+    }
+    d_nPiece = 0;
+    round *nx = nullptr;
+    if (!final) {
+        nx = free_round();
+        if (!nx) {
+            if (d_err.empty()) d_err = "no round free";
+            return false;
+        }
+        // every sync byte within a frame's longest span of the end goes along: its frame may reach past the end
+        size_t k = 0;
+        while (k < r.trig.size() && r.trig[k].pos + MAX_SPAN <= end) k++;
+        nx->trig.assign(r.trig.begin() + (long)k, r.trig.end());
+        nx->n_new = 0;
+        nx->n = 0;
+        nx->base = end;
+        if (!nx->trig.empty()) {
+            const uint64_t from = std::max(nx->trig[0].pos, r.base);
+            const size_t cnt = (size_t)(end - from);
+            if (!reserve(*nx, cnt)) {
+                d_err = "device memory for the held samples exhausted";
+                return false;
+            }
+            for (int a = 0; a < d_nrx; a++)
+                if (gr80211_copy_d2d_async(c, nx->iq[a], r.iq[a] + (size_t)(from - r.base) * sizeof(gr_complex),
+                                           cnt * sizeof(gr_complex), nullptr) != GR80211_OK) {
+                    d_err = r.gpu->error();
+                    return false;
+                }
+            // the next round's stream starts behind this copy
+            if (gr80211_stream_wait(nx->gpu->ctx(), nullptr, c, nullptr) != GR80211_OK) {
+                d_err = nx->gpu->error();
+                return false;
+            }
+            nx->base = from;
+            nx->n = cnt;
+        }
+        nx->state = round::FILL;
+    }
+    // ---- probe: L-SIG of every sync byte that has its 224 samples (lib/signal_impl.cc:108-131)
+    r.pd.clear();
+    r.p_of.assign(r.trig.size(), -1);
+    for (size_t j = 0; j < r.trig.size(); j++) {
+        const trigger &t = r.trig[j];
+        if (t.pos < r.base) continue;
+        const uint64_t rel = t.pos - r.base;
+        if (rel + LSIG_SPAN > r.n) continue;  // `signal` waits for 224 samples too
+        gr80211_frame_desc d;
+        memset(&d, 0, sizeof(d));
+        d.sync_off = rel;
+        d.n_avail = (uint32_t)std::min<uint64_t>(r.n - rel, 0xffffffffu);
+        d.rad = t.rad;
+        d.snr = t.snr;
+        d.rssi = t.rssi;
+        d.mu_pos = (uint32_t)d_muPos;
+        r.p_of[j] = (int32_t)r.pd.size();
+        r.pd.push_back(d);
+    }
+    if (!r.pd.empty()) {
+        const int np = (int)r.pd.size();
+        gr80211_frame_info *dinfo = static_cast<gr80211_frame_info *>(r.gpu->buffer(2, (size_t)np * sizeof(gr80211_frame_info)));
+        r.info = static_cast<gr80211_frame_info *>(r.gpu->staging(2, (size_t)np * sizeof(gr80211_frame_info)));
+        if (!dinfo || !r.info ||
+            gr80211_signal_batch(c, r.iq[0], d_nrx == 2 ? r.iq[1] : nullptr, r.n, r.pd.data(), np, 0, dinfo, nullptr) != GR80211_OK ||
+            gr80211_copy_d2h_async(c, r.info, dinfo, (size_t)np * sizeof(gr80211_frame_info), nullptr) != GR80211_OK) {
+            d_err = "probe of the sync bytes failed: " + r.gpu->error();
+            return false;
+        }
+    }
+    r.state = round::PROBE;
+    r.t_cut = now();
+    d_flight.push_back(&r);
+    d_nRounds++;
+    d_fill = nx;
+    return final ? true : advance(false, false);
+}
+
+// `signal`'s trigger search over one round, in stream order (lib/signal_impl.cc:75-106,153-160,164-202): the frames it
+// deals with go to r.fd.  Sync bytes it cannot settle yet (their frames reach past the round's end) were carried
+// over to the next round, which meets them again.
+bool rx::replay(round &r)
+{
+    const uint64_t end = r.base + r.n;
+    r.fd.clear();
+    r.fidx.clear();
+    r.fr.clear();
+    uint64_t want = 0;
+    for (size_t j = 0; j < r.trig.size(); j++) {
+        const trigger &t = r.trig[j];
+        if (t.pos < d_cursor) continue;  // inside the previous frame's span: `signal` never looks at it
+        const int32_t k = r.p_of[j];
+        if (k < 0) {  // fewer than 224 samples in this round: the next one has it, or the stream ends here
+            if (!r.final) want = t.pos + LSIG_SPAN;
+            break;
+        }
+        const gr80211_frame_info &fi = r.info[k];
+        if (fi.status == GR80211_ST_DROP_LSIG) {
+            d_cursor = t.pos + LSIG_FAIL_SKIP;
+            continue;
+        }
+        const int nsamp = fi.nsamp > 0 ? fi.nsamp : 0;
+        const uint64_t span = (uint64_t)LSIG_SPAN + (uint64_t)nsamp;
+        if (t.pos + span > end && !r.final) {  // its samples are still arriving
+            want = t.pos + span;
+            break;
+        }
+        gr80211_frame_desc d = r.pd[(size_t)k];
+        d.n_avail = (uint32_t)std::min<uint64_t>(span, end - t.pos);
+        r.fd.push_back(d);
+        r.fidx.push_back(k);
+        frame_ref fr;
+        fr.pos = t.pos;
+        fr.mcs = fi.lsig_mcs;
+        fr.len = fi.lsig_len;
+        fr.nsamp = nsamp;
+        fr.rad = t.rad;
+        fr.snr = t.snr;
+        fr.rssi = t.rssi;
+        r.fr.push_back(fr);
+        d_cursor = t.pos + span;
+    }
+    d_wantEnd = want;
+    r.t_replay = now();
+    if (!r.fd.empty() && !start_frames(r)) return false;
+    r.state = round::DECODE;
+    return true;
+}
+
+// Moves the rounds in flight on: a probed round whose records have arrived is searched and its frames are started (in
+// stream order: the search position carries over from round to round), the oldest round is published when its stream
+// has run dry.  wait_front: wait for the oldest round and retire it; wait_all: retire all.
+bool rx::advance(bool wait_front, bool wait_all)
+{
+    // 1. searches, oldest round first
+    for (round *r : d_flight) {
+        if (r->state != round::PROBE) continue;
+        if (!r->gpu->idle()) {
+            if (!(wait_all || (wait_front && r == d_flight.front()))) break;
+            if (!r->gpu->sync()) {
+                d_err = r->gpu->error();
+                return false;
+            }
+        }
+        if (!replay(*r)) return false;
+    }
+    // 2. the oldest rounds leave
+    while (!d_flight.empty() && d_flight.front()->state == round::DECODE) {
+        round *r = d_flight.front();
+        if (!r->gpu->idle()) {
+            if (!(wait_front || wait_all)) break;
+            if (!r->gpu->sync()) {
+                d_err = r->gpu->error();
+                return false;
+            }
+        }
+        if (!r->fd.empty() && !finish_frames(*r)) return false;
+        if (d_profile)
+            fprintf(stderr, "round %d: %zu items, %zu frames; cut %.4f searched %.4f published %.4f (in flight with %zu)\n",
+                    (int)(r - d_round), r->n, r->fd.size(), r->t_cut, r->t_replay, now(), d_flight.size() - 1);
+        r->trig.clear();
+        r->n = 0;
+        r->n_new = 0;
+        r->state = round::FREE;
+        d_flight.pop_front();
+        wait_front = false;  // only the oldest is waited for
+    }
+    return true;
+}
+
+bool rx::flush()
+{
+    if (!d_err.empty()) return false;
+    if (!d_up.drain()) {
+        d_err = "upload of the samples failed";
+        return false;
+    }
+    if (d_fill && (d_fill->n > 0 || !d_fill->trig.empty())) {
+        if (!cut(true)) return false;
+    }
+    if (!advance(true, true)) return false;
+    // ready for another stream
+    if (!d_fill) {
+        d_fill = &d_round[0];
+        d_fill->state = round::FILL;
+        d_fill->n = 0;
+        d_fill->n_new = 0;
+        d_fill->trig.clear();
+    }
+    return true;
+}
+
+// rx: demodulator and decoder for the round's frames, then the PDU slots on their way back; nothing is waited for
+bool rx::start_frames(round &r)
+{
+    gr80211_ctx *c = r.gpu->ctx();
+    const int nf = (int)r.fd.size();
+    uint8_t *dout = static_cast<uint8_t *>(r.gpu->buffer(3, (size_t)nf * OUT_STRIDE));
+    int32_t *dlen = static_cast<int32_t *>(r.gpu->buffer(4, (size_t)nf * 4));
+    int32_t *dnp = static_cast<int32_t *>(r.gpu->buffer(5, (size_t)nf * 4));
+    uint8_t *out = static_cast<uint8_t *>(r.gpu->staging(0, (size_t)nf * OUT_STRIDE));
+    int32_t *len = static_cast<int32_t *>(r.gpu->staging(1, (size_t)nf * 4));
     if (!dout || !dlen || !dnp || !out || !len) {
         d_err = "allocation of the output buffers failed";
         return false;
     }
-    if (gr80211_rx_batch(c, diq0, diq1, nheld, fd.data(), nf, 0, dout, OUT_STRIDE, dlen, dnp, nullptr, nullptr) !=
-            GR80211_OK ||
-        gr80211_copy_d2h(c, len, dlen, (size_t)nf * 4, nullptr) != GR80211_OK ||
-        gr80211_copy_d2h(c, out, dout, (size_t)nf * OUT_STRIDE, nullptr) != GR80211_OK) {
-        d_err = d_gpu.error();
+    if (gr80211_rx_resume(c, r.iq[0], d_nrx == 2 ? r.iq[1] : nullptr, r.n, r.fd.data(), r.fidx.data(), r.info, nf, dout,
+                          OUT_STRIDE, dlen, dnp, nullptr, nullptr) != GR80211_OK ||
+        gr80211_copy_d2h_async(c, len, dlen, (size_t)nf * 4, nullptr) != GR80211_OK ||
+        gr80211_copy_d2h_async(c, out, dout, (size_t)nf * OUT_STRIDE, nullptr) != GR80211_OK) {
+        d_err = r.gpu->error();
         return false;
     }
+    return true;
+}
+
+bool rx::finish_frames(round &r)
+{
+    const int nf = (int)r.fd.size();
+    if (gr80211_last_batch_refused(r.gpu->ctx()) != 0) {
+        d_err = "the GPU refused a batch: the frame records on the host do not describe it";
+        return false;
+    }
+    const uint8_t *out = static_cast<const uint8_t *>(r.gpu->staging(0, (size_t)nf * OUT_STRIDE));
+    const int32_t *len = static_cast<const int32_t *>(r.gpu->staging(1, (size_t)nf * 4));
     d_nFrames += (uint64_t)nf;
+    stopwatch sw(d_tPublish);
     d_nPdu += publish_slots(out, len, nf, OUT_STRIDE);
     return true;
 }
@@ -683,10 +1051,15 @@ int signal::general_work(int noutput_items, gr_vector_int &ninput_items, gr_vect
     return produced;
 }
 
-// signal: the frames' items and tags go to the output queues
-bool signal::handle_frames(const void *diq0, const void *diq1, size_t nheld, std::vector<gr80211_frame_desc> &fd,
-                           const std::vector<frame_ref> &fr)
+// signal: the frames' items and tags go to the output queues (at once: the items leave as the scheduler makes room)
+bool signal::start_frames(round &r)
 {
+    // the round's own context runs the batch: its stream holds the samples' copies
+    gpu_session &d_gpu = *r.gpu;
+    const void *diq0 = r.iq[0], *diq1 = d_nrx == 2 ? r.iq[1] : nullptr;
+    const size_t nheld = r.n;
+    std::vector<gr80211_frame_desc> &fd = r.fd;
+    const std::vector<frame_ref> &fr = r.fr;
     gr80211_ctx *c = d_gpu.ctx();
     const int nf = (int)fd.size();
     std::vector<uint64_t> off((size_t)nf + 1, 0);
@@ -926,7 +1299,7 @@ capture_rx::capture_rx(int n_rx, int device)
     if (!d_gpu.ok()) d_err = "gr80211_create failed";
 }
 
-capture_rx::~capture_rx() {}
+capture_rx::~capture_rx() { unpin_all(); }
 
 void capture_rx::forecast(int noutput_items, gr_vector_int &ninput_items_required)
 {

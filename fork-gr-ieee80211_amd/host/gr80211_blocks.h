@@ -19,6 +19,7 @@
 // are pending, when flush() is called, or when the sample hold reaches its limit.
 #pragma once
 
+#include <chrono>
 #include <complex>
 #include <cstdint>
 #include <deque>
@@ -77,12 +78,27 @@ public:
     // takes them with every call
     std::vector<tag_t> take_output_tags(int port);
     const std::string &last_error() const { return d_err; }
+    // Page-locked stream buffers.  Windows that lie in page-locked memory travel to the GPU by asynchronous DMA at the
+    // rate of the link instead of through the runtime's staging copies; their items are consumed once their copy has
+    // run, so a call may consume fewer items than it was offered (it always consumes some).  Two ways to get there:
+    // alloc_input hands out such a buffer for the scheduler to use as the block's input buffer (what a GNU Radio 3.10
+    // custom buffer type does; freed by free_input or with the block), pin_input page-locks a buffer the scheduler
+    // already owns (not every system lets user pages be locked: false then, and ordinary copies are used).
+    void *alloc_input(size_t bytes);
+    void free_input(void *p);
+    bool pin_input(const void *p, size_t bytes);
 
 protected:
     explicit block(int n_in, int n_out = 0);
+    virtual gr80211_ctx *pin_context() { return nullptr; }  // the context page-locking goes through
+    bool is_pinned(const void *p, size_t bytes) const;
+    void unpin_all();
     void consume_each(int n) { d_consumed = n; }
     void add_item_tag(int port, const tag_t &t) { d_out_tags[port].push_back(t); }
     void get_tags_in_range(std::vector<tag_t> &v, int port, uint64_t start, uint64_t end) const;
+    // The values of the tags `keys` on item `offset` of `port` (the last tag of a key wins, as pmt::dict_add overwrites)
+    // without copying tags; false if the item carries no tag at all.  out[k] keeps its value where key k is missing.
+    bool tag_values_at(int port, uint64_t offset, const char *const *keys, double *out, int n_keys) const;
     void message_port_pub(const std::string &port, const pdu_t &m);
     // Publishes the messages n frame slots hold (stride bytes apart, len[i] bytes used); returns how many.
     uint64_t publish_slots(const uint8_t *out, const int32_t *len, int n, int stride);
@@ -94,6 +110,10 @@ private:
     std::vector<std::deque<tag_t>> d_tags;  // per port, sorted by offset; passed tags leave at the front
     int d_consumed = 0;
     std::function<void(const std::string &, const pdu_t &)> d_handler;
+    pdu_t d_msg;  // publish_slots builds every message here: no allocation per message once it has grown
+    std::vector<std::pair<const char *, size_t>> d_pinned;  // ranges known to be page-locked
+    std::vector<void *> d_owned;                            // ... of which alloc_input made these
+    std::vector<const char *> d_registered;                 // ... and pin_input locked these
 };
 
 // Owns a gr80211 context and a few growable device buffers.
@@ -111,6 +131,8 @@ public:
     gr80211_ctx *ctx() const { return d_ctx; }
     void *buffer(int slot, size_t bytes);  // device buffer `slot` of at least `bytes` (contents not preserved)
     void *staging(int slot, size_t bytes);  // page-locked host buffer `slot`, same rules
+    bool idle() const { return d_ctx && gr80211_stream_idle(d_ctx, nullptr) == 1; }   // the context's stream has run dry
+    bool sync() const { return d_ctx && gr80211_sync(d_ctx, nullptr) == GR80211_OK; }
     std::string error() const;
 
 private:
@@ -120,7 +142,34 @@ private:
         size_t cap = 0;
     };
     dbuf d_buf[8];
-    dbuf d_stage[4];
+    dbuf d_stage[6];
+};
+
+// Input items whose copies to the GPU are still on their way: general_work consumes a window's items only once their
+// copy has run (the scheduler may overwrite consumed items at once).  Entries are in stream order.
+class upload_log
+{
+public:
+    uint64_t enqueued() const { return d_enq; }  // absolute index up to which input has been taken
+    void set_enqueued(uint64_t v) { d_enq = v; }
+    // items up to `upto` are free once copy `id` of `g` has read its source: a gr80211_pull_h2d number (pull) or a
+    // marker behind a runtime copy; g == nullptr: at once
+    void add(gpu_session *g, long long id, uint64_t upto, bool pull = false) { d_q.push_back({g, id, upto, pull}); }
+    // absolute index up to which items may be consumed, at least `from`; waits for the oldest copy if nothing beyond
+    // `from` is free yet and something is on its way
+    uint64_t settled(uint64_t from);
+    bool drain();  // waits for every copy
+    bool empty() const { return d_q.empty(); }
+
+private:
+    struct entry {
+        gpu_session *g;
+        long long id;
+        uint64_t upto;
+        bool pull;
+    };
+    std::deque<entry> d_q;
+    uint64_t d_enq = 0;
 };
 
 // Items waiting for the GPU, kept in device memory: every window of the stream is uploaded when it arrives, so the
@@ -188,6 +237,9 @@ public:
     uint64_t packets_seen() const { return d_nSeen; }
     uint64_t pdus_published() const { return d_nPdu; }
 
+protected:
+    gr80211_ctx *pin_context() override { return d_gpu.ctx(); }
+
 private:
     decode(bool ifdebug, int batch_frames, int device);
     bool run_batch();
@@ -221,41 +273,80 @@ public:
 
     // this station's position in VHT MU groups: the mupos argument of ieee80211::demod::make (lib/demod_impl.cc:28-39)
     void set_mu_pos(int pos) { d_muPos = pos ? 1 : 0; }
-    void set_ampdu_strict(bool on) { d_gpu.set_ampdu_strict(on); }
+    void set_ampdu_strict(bool on);
+    // samples a round holds at most before it is cut whatever the trigger count (at least four frame spans)
+    void set_max_hold(size_t items);
     uint64_t triggers_seen() const { return d_nTrig; }
     uint64_t frames_decoded() const { return d_nFrames; }
     uint64_t pdus_published() const { return d_nPdu; }
+    uint64_t rounds_cut() const { return d_nRounds; }
 
 protected:
     rx(int n_rx, int batch_frames, int device, int n_out = 0);
+    gr80211_ctx *pin_context() override { return d_gpu.ctx(); }
     struct frame_ref {
         uint64_t pos;  // absolute item index of the trigger byte
         int mcs, len, nsamp;
         float rad, snr, rssi;
     };
-    // What becomes of the frames of one round: fd[i] describes frame i in the device arenas diq0 / diq1 (nheld items
-    // each).  rx decodes them and publishes their PDUs.
-    virtual bool handle_frames(const void *diq0, const void *diq1, size_t nheld, std::vector<gr80211_frame_desc> &fd,
-                               const std::vector<frame_ref> &fr);
-    int take_input(gr_vector_int &ninput_items, gr_vector_const_void_star &input_items);  // items consumed, -1 on error
-    bool process(bool final);
-
     struct trigger {
         uint64_t pos;  // absolute item index of the sync byte
         float rad, snr, rssi;
-        bool probed;
-        int status, nsamp, mcs, len;
     };
+    // One stretch of the stream on its way through the GPU.  Rounds follow each other: while one is filled with the
+    // windows that arrive, the ones before it are probed (L-SIG of every sync byte), searched (`signal`'s trigger
+    // search, on the host), decoded and published, each on the stream of a context of its own.
+    struct round {
+        std::unique_ptr<gpu_session> gpu;
+        char *iq[2] = {nullptr, nullptr};  // device arenas, one per antenna
+        size_t cap = 0, n = 0;             // items they can hold / hold
+        uint64_t base = 0;                 // absolute index of item 0
+        std::vector<trigger> trig;         // sync bytes inside, in stream order
+        size_t n_new = 0;                  // ... of which arrived while this round was filled (the rest were carried over)
+        enum { FREE, FILL, PROBE, DECODE } state = FREE;
+        bool final = false;
+        std::vector<gr80211_frame_desc> pd;  // probe: one per sync byte with its 224 samples
+        std::vector<int32_t> p_of;           // sync byte -> place in pd, or -1
+        gr80211_frame_info *info = nullptr;  // page-locked: the records of pd
+        std::vector<gr80211_frame_desc> fd;  // the frames `signal` deals with
+        std::vector<int32_t> fidx;           // their places in pd
+        std::vector<frame_ref> fr;
+        double t_cut = 0, t_replay = 0;      // profile: seconds since the block was made
+    };
+    // What becomes of the frames of a round: rx starts demodulator and decoder and the copy of the PDU slots back
+    // (nothing waited for) and publishes them in finish_frames once the round's stream has run dry.
+    virtual bool start_frames(round &r);
+    virtual bool finish_frames(round &r);
+    int take_input(gr_vector_int &ninput_items, gr_vector_const_void_star &input_items);  // items consumed, -1 on error
+    bool cut(bool final);
+    bool advance(bool wait_front, bool wait_all);
+    bool replay(round &r);
+    bool reserve(round &r, size_t items);
+    round *free_round();
+
     int d_nrx, d_batch;
     int d_muPos = 0;
-    gpu_session d_gpu;
-    device_fifo d_hold0, d_hold1;         // samples not yet released, one queue per antenna
-    device_fifo &hold(int a) { return a ? d_hold1 : d_hold0; }
-    uint64_t d_base = 0;                // absolute item index of d_hold[*][0]
+    gpu_session d_gpu;                  // page-locking, options; its stream carries every other upload
+    gpu_session d_gpu2;                 // the stream of the uploads in between: two pieces are on the link at a time, and
+                                        // none of them queues behind a round's decoder
+    unsigned d_nPiece = 0;              // uploads since the last cut
+    int d_firstSplit = 0;               // pieces a window that finds nothing on its way is cut into (0: by its size)
+    static constexpr int N_ROUNDS = 4;
+    round d_round[N_ROUNDS];
+    round *d_fill = nullptr;
+    std::deque<round *> d_flight;       // rounds being probed / decoded, oldest first
+    upload_log d_up;
     uint64_t d_cursor = 0;              // absolute index where the trigger search resumes (lib/signal_impl.cc:75-106)
-    std::vector<trigger> d_trig;
+    uint64_t d_wantEnd = 0;             // stream position at which the oldest carried-over frame is complete (0: none known)
     size_t d_maxHold;
-    uint64_t d_nTrig = 0, d_nFrames = 0, d_nPdu = 0;
+    bool d_strict = false;
+    uint64_t d_nTrig = 0, d_nFrames = 0, d_nPdu = 0, d_nRounds = 0;
+    // where the host's time goes (seconds), printed when the block goes if GR80211_BLOCK_PROFILE is set
+    double d_tScan = 0, d_tUpload = 0, d_tSettle = 0, d_tAdvance = 0, d_tCut = 0, d_tPublish = 0;
+    uint64_t d_nCalls = 0;
+    bool d_profile = false;
+    std::chrono::steady_clock::time_point d_t0 = std::chrono::steady_clock::now();
+    double now() const { return std::chrono::duration<double>(std::chrono::steady_clock::now() - d_t0).count(); }
 };
 
 // ieee80211::signal (n_rx = 1: in {u8 sync, c64}, out {c64}) and signal2 (n_rx = 2: in {u8, c64, c64}, out {c64, c64}),
@@ -274,8 +365,8 @@ public:
 
 protected:
     signal(int n_rx, int batch_frames, int device);
-    bool handle_frames(const void *diq0, const void *diq1, size_t nheld, std::vector<gr80211_frame_desc> &fd,
-                       const std::vector<frame_ref> &fr) override;
+    bool start_frames(round &r) override;
+    bool finish_frames(round &) override { return true; }
 
 private:
     out_stream d_out0, d_out1;
@@ -292,6 +383,7 @@ class demod : public block
 public:
     typedef std::shared_ptr<demod> sptr;
     static sptr make(int n_rx = 1, int mupos = 0, int mugid = 2, int batch_frames = 4096, int device = 0);
+    ~demod() override { unpin_all(); }
     void forecast(int noutput_items, gr_vector_int &ninput_items_required) override;
     int general_work(int noutput_items, gr_vector_int &ninput_items, gr_vector_const_void_star &input_items,
                      gr_vector_void_star &output_items) override;
@@ -299,6 +391,9 @@ public:
     size_t pending_output() const { return d_out.pending(); }
     uint64_t frames_seen() const { return d_nSeen; }
     void set_mu_pos(int pos) { d_muPos = pos ? 1 : 0; }
+
+protected:
+    gr80211_ctx *pin_context() override { return d_gpu.ctx(); }
 
 private:
     demod(int n_rx, int mupos, int batch_frames, int device);
@@ -335,6 +430,9 @@ public:
     void set_ampdu_strict(bool on) { d_gpu.set_ampdu_strict(on); }
     uint64_t frames_decoded() const { return d_nFrames; }
     uint64_t pdus_published() const { return d_nPdu; }
+
+protected:
+    gr80211_ctx *pin_context() override { return d_gpu.ctx(); }
 
 private:
     capture_rx(int n_rx, int device);

@@ -39,6 +39,37 @@ static bool read_file(const char *path, std::vector<char> &out)
     return ok;
 }
 
+// A stream held in memory the block handed out as its input buffer (page-locked: what a GNU Radio 3.10 custom
+// buffer type gives the scheduler), or in ordinary memory with GR80211_PUMP_PIN=0 in the environment (what a wrapper
+// that leaves the buffers to the scheduler hands over).
+struct stream_buf {
+    block *owner = nullptr;
+    char *p = nullptr;
+    std::vector<char> plain;
+    size_t bytes = 0;
+    const char *data() const { return p ? p : plain.data(); }
+    size_t size() const { return bytes; }
+    bool load(block &b, const char *path)
+    {
+        std::vector<char> tmp;
+        if (!read_file(path, tmp)) return false;
+        bytes = tmp.size();
+        const char *pin = getenv("GR80211_PUMP_PIN");
+        if ((!pin || pin[0] != '0') && bytes) p = static_cast<char *>(b.alloc_input(bytes));
+        if (p) {
+            owner = &b;
+            memcpy(p, tmp.data(), bytes);
+        } else {
+            plain.swap(tmp);
+        }
+        return true;
+    }
+    ~stream_buf()
+    {
+        if (p && owner) owner->free_input(p);
+    }
+};
+
 static bool g_quiet = false;
 static double g_seconds = 0.0;
 
@@ -155,15 +186,19 @@ int main(int argc, char **argv)
     if (const char *q = getenv("GR80211_PUMP_QUIET")) g_quiet = q[0] == '1';
     if (argc >= 7 && !strcmp(argv[1], "rx")) {
         const int n_rx = atoi(argv[2]), chunk = atoi(argv[3]), batch = atoi(argv[4]);
-        std::vector<char> iq0, iq1;
-        if (!read_file(argv[6], iq0) || (n_rx == 2 && (argc < 8 || !read_file(argv[7], iq1)))) {
+        rx::sptr b = rx::make(n_rx, batch, 0);
+        if (!b->last_error().empty()) {
+            fprintf(stderr, "block error: %s\n", b->last_error().c_str());
+            return 1;
+        }
+        stream_buf iq0, iq1;
+        if (!iq0.load(*b, argv[6]) || (n_rx == 2 && (argc < 8 || !iq1.load(*b, argv[7])))) {
             fprintf(stderr, "cannot read IQ file\n");
             return 2;
         }
         size_t n = iq0.size() / 8;
         if (n_rx == 2) n = std::min(n, iq1.size() / 8);
         std::vector<char> sync(n, 0);
-        rx::sptr b = rx::make(n_rx, batch, 0);
         b->set_msg_handler(on_msg);
         FILE *f = fopen(argv[5], "r");
         if (!f) return 2;
@@ -255,14 +290,14 @@ int main(int argc, char **argv)
     }
     if (argc >= 5 && !strcmp(argv[1], "capture")) {
         const int n_rx = atoi(argv[2]), chunk = atoi(argv[3]);
-        std::vector<char> iq0, iq1;
-        if (!read_file(argv[4], iq0) || (n_rx == 2 && (argc < 6 || !read_file(argv[5], iq1)))) {
+        capture_rx::sptr b = capture_rx::make(n_rx, 0);
+        stream_buf iq0, iq1;
+        if (!iq0.load(*b, argv[4]) || (n_rx == 2 && (argc < 6 || !iq1.load(*b, argv[5])))) {
             fprintf(stderr, "cannot read IQ file\n");
             return 2;
         }
         size_t n = iq0.size() / 8;
         if (n_rx == 2) n = std::min(n, iq1.size() / 8);
-        capture_rx::sptr b = capture_rx::make(n_rx, 0);
         b->set_msg_handler(on_msg);
         std::vector<const char *> ports = {iq0.data()};
         std::vector<size_t> isz = {8};
@@ -278,13 +313,17 @@ int main(int argc, char **argv)
     }
     if (argc >= 6 && !strcmp(argv[1], "decode")) {
         const int chunk = atoi(argv[2]), batch = atoi(argv[3]);
-        std::vector<char> llr;
-        if (!read_file(argv[5], llr)) {
+        decode::sptr b = decode::make(false, batch, 0);
+        if (!b->last_error().empty()) {
+            fprintf(stderr, "block error: %s\n", b->last_error().c_str());
+            return 1;
+        }
+        stream_buf llr;
+        if (!llr.load(*b, argv[5])) {
             fprintf(stderr, "cannot read LLR file\n");
             return 2;
         }
         const size_t n = llr.size() / 4;
-        decode::sptr b = decode::make(false, batch, 0);
         b->set_msg_handler(on_msg);
         FILE *f = fopen(argv[4], "r");
         if (!f) return 2;

@@ -370,6 +370,14 @@ int gr80211_copy_d2d(gr80211_ctx *ctx, void *d_dst, const void *d_src, size_t by
  * and kernels in flight (GNU Radio gives a block one thread; no counterpart in the reference, whose blocks compute on
  * that thread).  Host memory of an asynchronous copy must be page-locked (gr80211_host_alloc, gr80211_host_register)
  * and stay untouched until the copy has run.
+ *   gr80211_pull_h2d       host-to-device copy done by a kernel that reads page-locked host memory over the link (memory
+ *                          from gr80211_host_alloc; fastest with both ends 16-byte aligned, any alignment works): the
+ *                          host pays one kernel launch whatever the size, and pieces below about 1 MB move faster than
+ *                          by the runtime's copy engine (256 KiB: 32 GB/s against 18).  Returns the copy's number
+ *                          (>= 1) or a negative code.
+ *   gr80211_pull_done      1 if copy `number` has read all of its source (the source may be overwritten), 0 if not;
+ *                          wait != 0: spin until it has.  Numbers arrive in order when a context's pulls all go to one
+ *                          stream; the destination is ready for work enqueued on that stream after the pull, as usual.
  *   gr80211_stream_idle    1 if the stream has run everything enqueued on it, 0 if not (no wait).
  *   gr80211_stream_wait    work enqueued on (ctx, stream) from now on starts after what (other, other_stream) holds now.
  *   gr80211_marker_record  marks the current end of the stream's queue; returns the marker's number (>= 0).
@@ -379,6 +387,8 @@ int gr80211_copy_d2d(gr80211_ctx *ctx, void *d_dst, const void *d_src, size_t by
  *                          registered, so that copies from it run asynchronously at the rate of the link.
  */
 int gr80211_copy_h2d_async(gr80211_ctx *ctx, void *d_dst, const void *h_src, size_t bytes, void *stream);
+long long gr80211_pull_h2d(gr80211_ctx *ctx, void *d_dst, const void *h_src, size_t bytes, void *stream);
+int gr80211_pull_done(gr80211_ctx *ctx, long long number, int wait);
 int gr80211_copy_d2h_async(gr80211_ctx *ctx, void *h_dst, const void *d_src, size_t bytes, void *stream);
 int gr80211_copy_d2d_async(gr80211_ctx *ctx, void *d_dst, const void *d_src, size_t bytes, void *stream); /* no overlap */
 int gr80211_stream_idle(gr80211_ctx *ctx, void *stream);

@@ -16,8 +16,9 @@ sys.path.insert(0, ROOT)
 PUMP = os.path.join(ROOT, "fork-gr-ieee80211_amd", "gr80211_pump")
 
 
-def run(args, n_samples, label):
-    env = dict(os.environ, GR80211_PUMP_QUIET="1")
+def run(args, n_samples, label, pin=True):
+    env = dict(os.environ, GR80211_PUMP_QUIET="1", GR80211_PUMP_PIN="1" if pin else "0")
+    label += "  page-locked buffers" if pin else "  ordinary buffers   "
     p = subprocess.run([PUMP] + [str(a) for a in args], capture_output=True, text=True, env=env, timeout=300)
     stat = [l for l in p.stdout.splitlines() if l.startswith("STAT")]
     tm = [l for l in p.stdout.splitlines() if l.startswith("TIME")]
@@ -62,12 +63,15 @@ def main():
     torch.cuda.empty_cache()
     ns = n * L
     print("%d VHT MCS8 frames, %d samples per antenna, %.0f MB of IQ" % (n, ns, ns * 8 / 1e6), flush=True)
-    for chunk, batch in ((8192, 4096), (65536, 4096), (65536, 16384), (1 << 20, 16384)):
-        run(["rx", 1, chunk, batch, f_tr, f_iq], ns, "rx      window %7d batch %5d" % (chunk, batch))
-    run(["chain", 1, 65536, 4096, f_tr, f_iq], ns, "signal->demod->decode, 65536/4096")
+    for pin in (True, False):
+        for chunk, batch in ((8192, 4096), (65536, 4096), (65536, 16384), (1 << 20, 16384)):
+            run(["rx", 1, chunk, batch, f_tr, f_iq], ns, "rx      window %7d batch %5d" % (chunk, batch), pin)
+    if n <= 20000:
+        run(["chain", 1, 65536, 4096, f_tr, f_iq], ns, "signal->demod->decode, 65536/4096")
     run(["capture", 1, 65536, f_iq], ns, "capture window   65536")
-    for chunk, batch in ((65536, 4096), (1 << 20, 16384)):
-        run(["decode", chunk, batch, f_tg, f_llr], ns, "decode  window %7d batch %5d" % (chunk, batch))
+    for pin in (True, False):
+        for chunk, batch in ((65536, 4096), (65536, 16384), (1 << 20, 16384)):
+            run(["decode", chunk, batch, f_tg, f_llr], ns, "decode  window %7d batch %5d" % (chunk, batch), pin)
     for f in (f_iq, f_tr, f_llr, f_tg):
         os.remove(f)
 
