@@ -64,6 +64,15 @@ struct gr80211_ctx {
     unsigned *pull_ctr_d = nullptr;         // device: workgroups of the running pull copy that have finished
     long long pull_seq = 0;
     void *pull_flag_view = nullptr;         // the flag word as the GPU addresses it
+    // Descriptors the caller keeps in ordinary host memory travel through page-locked memory of the context: the
+    // runtime's copy from ordinary memory waits for everything its hardware queue holds, other streams' decoders included.
+    struct HostStage {
+        void *p = nullptr;
+        size_t cap = 0;
+        hipEvent_t ev = nullptr;  // end of the last copy out of p
+        bool used = false;
+    } hstage[4];
+    unsigned hstage_next = 0;
     uintptr_t pull_lo = 0, pull_hi = 0;     // the page-locked range the last pull copy read from ...
     intptr_t pull_to_dev = 0;               // ... and what turns its host addresses into the GPU's
     static constexpr int N_MARK = 256;
@@ -344,6 +353,31 @@ int run_decode_stages(gr80211_ctx *c, hipStream_t s, int n, bool from_iq, const 
                                 d_n_pdu, d_bits, bits_stride, decode, llr_used, llr_floats, known);
 }
 
+// Host memory of any kind to the device, asynchronously: the bytes are copied to page-locked memory of the context
+// first (the caller's array is free on return), one of four areas in turn, each waited for before it is used again.
+int upload_small(gr80211_ctx *c, hipStream_t s, void *d_dst, const void *h_src, size_t bytes)
+{
+    gr80211_ctx::HostStage &h = c->hstage[c->hstage_next++ & 3];
+    if (!h.ev && hipEventCreateWithFlags(&h.ev, hipEventDisableTiming) != hipSuccess) return fail(c, GR80211_ERR_HIP, "hipEventCreate");
+    if (h.used) HIP_TRY(c, hipEventSynchronize(h.ev));
+    if (bytes > h.cap) {
+        if (h.p) (void)hipHostFree(h.p);
+        h.p = nullptr;
+        h.cap = 0;
+        const size_t cap = bytes + bytes / 2 + 4096;
+        if (hipHostMalloc(&h.p, cap) != hipSuccess) {
+            h.p = nullptr;
+            return fail(c, GR80211_ERR_NOMEM, "page-locked memory for the descriptors");
+        }
+        h.cap = cap;
+    }
+    memcpy(h.p, h_src, bytes);
+    HIP_TRY(c, hipMemcpyAsync(d_dst, h.p, bytes, hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipEventRecord(h.ev, s));
+    h.used = true;
+    return GR80211_OK;
+}
+
 int stage_desc(gr80211_ctx *c, hipStream_t s, const void *desc, size_t bytes, unsigned flags, Buf &dst, const void **out)
 {
     if (flags & GR80211_FLAG_DESC_ON_DEVICE) {
@@ -352,7 +386,7 @@ int stage_desc(gr80211_ctx *c, hipStream_t s, const void *desc, size_t bytes, un
     }
     int rc = ensure(c, dst, bytes);
     if (rc) return rc;
-    HIP_TRY(c, hipMemcpyAsync(dst.p, desc, bytes, hipMemcpyHostToDevice, s));
+    if ((rc = upload_small(c, s, dst.p, desc, bytes))) return rc;
     *out = dst.p;
     return GR80211_OK;
 }
@@ -466,6 +500,7 @@ __global__ __launch_bounds__(256) void k_pull(V *__restrict__ dst, const V *__re
         dst[i] = __builtin_nontemporal_load(src + i);
     if (blockIdx.x == 0 && (int)threadIdx.x < n_tail) dst_tail[threadIdx.x] = src_tail[threadIdx.x];
     // every load of this workgroup has returned once its threads are here (each store above needed its load's data)
+    if (!flag) return;  // a copy nobody waits for by number
     __syncthreads();
     if (threadIdx.x == 0) {
         const unsigned before = __hip_atomic_fetch_add(finished, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
@@ -474,6 +509,31 @@ __global__ __launch_bounds__(256) void k_pull(V *__restrict__ dst, const V *__re
             __hip_atomic_store(flag, number, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
+}
+
+// Launches the copy kernel with the widest element both addresses are aligned to: 16 bytes, 8 (a stream of complex
+// samples cut at an odd item), 4 or 1.
+void launch_link_copy(void *dst, const void *src, size_t bytes, unsigned *finished, uint32_t *flag, uint32_t number, hipStream_t on)
+{
+    const uintptr_t both = (uintptr_t)src | (uintptr_t)dst;
+    const int width = !(both & 15) ? 16 : !(both & 7) ? 8 : !(both & 3) ? 4 : 1;
+    const size_t n_wide = bytes / width;
+    const int n_tail = (int)(bytes - n_wide * width);
+    size_t blocks = (n_wide + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    unsigned char *dt = (unsigned char *)dst + n_wide * width;
+    const unsigned char *st = (const unsigned char *)src + n_wide * width;
+    const dim3 grid((unsigned)blocks), wg(256);
+    if (width == 16)
+        hipLaunchKernelGGL(k_pull<pull_u4>, grid, wg, 0, on, (pull_u4 *)dst, (const pull_u4 *)src, n_wide, dt, st, n_tail, finished, flag, number);
+    else if (width == 8)
+        hipLaunchKernelGGL(k_pull<pull_u2>, grid, wg, 0, on, (pull_u2 *)dst, (const pull_u2 *)src, n_wide, dt, st, n_tail, finished, flag, number);
+    else if (width == 4)
+        hipLaunchKernelGGL(k_pull<unsigned>, grid, wg, 0, on, (unsigned *)dst, (const unsigned *)src, n_wide, dt, st, n_tail, finished, flag, number);
+    else
+        hipLaunchKernelGGL(k_pull<unsigned char>, grid, wg, 0, on, (unsigned char *)dst, (const unsigned char *)src, n_wide, dt, st, n_tail,
+                           finished, flag, number);
 }
 }  // namespace
 
@@ -548,6 +608,10 @@ void gr80211_destroy(gr80211_ctx *c)
     if (c->det_totals_h) (void)hipHostFree(c->det_totals_h);
     if (c->na_desc_h) (void)hipHostFree(c->na_desc_h);
     if (c->pull_flag_h) (void)hipHostFree(c->pull_flag_h);
+    for (auto &h : c->hstage) {
+        if (h.p) (void)hipHostFree(h.p);
+        if (h.ev) (void)hipEventDestroy(h.ev);
+    }
     if (c->pull_ctr_d) (void)hipFree(c->pull_ctr_d);
     for (auto &e : c->ev)
         if (e) (void)hipEventDestroy(e);
@@ -835,6 +899,19 @@ int gr80211_decode_batch(gr80211_ctx *c, const float *d_llr, uint64_t llr_floats
     }
     int rc;
     const void *dd = nullptr;
+    // Descriptors on the host say what the scheduler kernels will arrive at: the work buffers are sized from them and
+    // nothing is waited for (descriptors on the device: the scheduler's totals are waited for, as before).
+    SchedTotals known = {};
+    const bool on_host = !(flags & GR80211_FLAG_DESC_ON_DEVICE);
+    if (on_host) {
+        known = host_schedule(n, [&](int i, bool *admitted, int *cr, int *trellis, long long *soft) {
+            const gr80211_dec_desc &d = desc[i];
+            *admitted = decoder_admits(d.cr, d.trellis, d.len, d.n_llr);
+            *cr = d.cr;
+            *trellis = d.trellis;
+            *soft = 0;
+        });
+    }
     if ((rc = stage_desc(c, s, desc, (size_t)n * sizeof(gr80211_dec_desc), flags, c->ddesc, &dd))) return rc;
     c->signal_n = 0;
     if ((rc = ensure(c, c->info, (size_t)n * sizeof(gr80211_frame_info)))) return rc;
@@ -842,7 +919,7 @@ int gr80211_decode_batch(gr80211_ctx *c, const float *d_llr, uint64_t llr_floats
     launch_desc_to_info((const gr80211_dec_desc *)dd, n, llr_floats, (gr80211_frame_info *)c->info.p, s);
     mark(c, 1, s);
     rc = run_decode_stages(c, s, n, false, nullptr, nullptr, 0, nullptr, d_llr, d_out, out_stride, d_out_len, d_n_pdu,
-                           d_bits, bits_stride, true, nullptr, nullptr);
+                           d_bits, bits_stride, true, nullptr, nullptr, on_host ? &known : nullptr);
     if (rc) return rc;
     return finish_timing(c, s);
 }
@@ -979,8 +1056,8 @@ int gr80211_rx_resume(gr80211_ctx *c, const void *d_iq0, const void *d_iq1, uint
     if ((rc = ensure(c, c->info_alt, (size_t)n * sizeof(gr80211_frame_info)))) return rc;
     if ((rc = ensure(c, c->chan1_alt, (size_t)n * 64 * 8))) return rc;
     if (d_iq1 && (rc = ensure(c, c->chan2_alt, (size_t)n * 520 * 8))) return rc;
-    HIP_TRY(c, hipMemcpyAsync(c->desc.p, h_desc, (size_t)n * sizeof(gr80211_frame_desc), hipMemcpyHostToDevice, s));
-    HIP_TRY(c, hipMemcpyAsync(c->sel_index.p, h_index, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    if ((rc = upload_small(c, s, c->desc.p, h_desc, (size_t)n * sizeof(gr80211_frame_desc)))) return rc;
+    if ((rc = upload_small(c, s, c->sel_index.p, h_index, (size_t)n * sizeof(int32_t)))) return rc;
     mark(c, 0, s);
     // the preamble has run over these frames already: their records and channels move to the front of the second
     // set of buffers, which takes the first set's place
@@ -1021,7 +1098,7 @@ long long gr80211_pull_h2d(gr80211_ctx *c, void *d_dst, const void *h_src, size_
     if (hipSetDevice(c->device) != hipSuccess) return fail(c, GR80211_ERR_HIP, "hipSetDevice");
     if (!c->pull_flag_h) {
         if (hipHostMalloc((void **)&c->pull_flag_h, 64) != hipSuccess || hipMalloc((void **)&c->pull_ctr_d, 64) != hipSuccess ||
-            hipMemset(c->pull_ctr_d, 0, 64) != hipSuccess)
+            hipMemsetAsync(c->pull_ctr_d, 0, 64, pick(c, stream)) != hipSuccess)
             return fail(c, GR80211_ERR_NOMEM, "gr80211_pull_h2d: set-up failed");
         *c->pull_flag_h = 0;
         if (hipHostGetDevicePointer(&c->pull_flag_view, c->pull_flag_h, 0) != hipSuccess) return fail(c, GR80211_ERR_HIP, "hipHostGetDevicePointer");
@@ -1044,32 +1121,8 @@ long long gr80211_pull_h2d(gr80211_ctx *c, void *d_dst, const void *h_src, size_
         }
     }
     void *flag_view = c->pull_flag_view;
-    // the widest element both addresses are aligned to: 16 bytes, 8 (a stream of complex samples cut at an odd item), 4 or 1
-    const uintptr_t both = (uintptr_t)dev_view | (uintptr_t)d_dst;
-    const int width = !(both & 15) ? 16 : !(both & 7) ? 8 : !(both & 3) ? 4 : 1;
-    const size_t n_wide = bytes / width;
-    const int n_tail = (int)(bytes - n_wide * width);
-    size_t blocks = (n_wide + 255) / 256;
-    if (blocks > 2048) blocks = 2048;
-    if (blocks < 1) blocks = 1;
     const long long number = ++c->pull_seq;
-    unsigned char *dt = (unsigned char *)d_dst + n_wide * width;
-    const unsigned char *st = (const unsigned char *)dev_view + n_wide * width;
-    const dim3 grid((unsigned)blocks), wg(256);
-    hipStream_t on = pick(c, stream);
-    uint32_t *fl = (uint32_t *)flag_view;
-    if (width == 16)
-        hipLaunchKernelGGL(k_pull<pull_u4>, grid, wg, 0, on, (pull_u4 *)d_dst, (const pull_u4 *)dev_view, n_wide, dt, st, n_tail,
-                           c->pull_ctr_d, fl, (uint32_t)number);
-    else if (width == 8)
-        hipLaunchKernelGGL(k_pull<pull_u2>, grid, wg, 0, on, (pull_u2 *)d_dst, (const pull_u2 *)dev_view, n_wide, dt, st, n_tail,
-                           c->pull_ctr_d, fl, (uint32_t)number);
-    else if (width == 4)
-        hipLaunchKernelGGL(k_pull<unsigned>, grid, wg, 0, on, (unsigned *)d_dst, (const unsigned *)dev_view, n_wide, dt, st, n_tail,
-                           c->pull_ctr_d, fl, (uint32_t)number);
-    else
-        hipLaunchKernelGGL(k_pull<unsigned char>, grid, wg, 0, on, (unsigned char *)d_dst, (const unsigned char *)dev_view, n_wide,
-                           dt, st, n_tail, c->pull_ctr_d, fl, (uint32_t)number);
+    launch_link_copy(d_dst, dev_view, bytes, c->pull_ctr_d, (uint32_t *)flag_view, (uint32_t)number, pick(c, stream));
     if (hipGetLastError() != hipSuccess) return fail(c, GR80211_ERR_HIP, "gr80211_pull_h2d: launch failed");
     return number;
 }
@@ -1092,6 +1145,28 @@ int gr80211_pull_done(gr80211_ctx *c, long long number, int wait)
         __builtin_ia32_pause();
     }
     return 1;
+}
+
+int gr80211_push_d2h(gr80211_ctx *c, void *h_dst, const void *d_src, size_t bytes, void *stream)
+{
+    if (!c) return GR80211_ERR_ARG;
+    if (!bytes) return GR80211_OK;
+    if (!h_dst || !d_src) return fail(c, GR80211_ERR_ARG, "gr80211_push_d2h: bad argument");
+    HIP_TRY(c, hipSetDevice(c->device));
+    void *dev_view = nullptr;
+    HostRange r{0, 0, 0};
+    if (host_range_of(h_dst, bytes, &r)) {
+        dev_view = (void *)((uintptr_t)h_dst + r.to_dev);
+    } else {
+        const hipError_t e = hipHostGetDevicePointer(&dev_view, h_dst, 0);
+        if (e != hipSuccess || !dev_view) {
+            (void)hipGetLastError();
+            return fail(c, GR80211_ERR_ARG, "gr80211_push_d2h: the destination is not page-locked host memory the GPU can write", e);
+        }
+    }
+    launch_link_copy(dev_view, d_src, bytes, nullptr, nullptr, 0, pick(c, stream));
+    if (hipGetLastError() != hipSuccess) return fail(c, GR80211_ERR_HIP, "gr80211_push_d2h: launch failed");
+    return GR80211_OK;
 }
 
 int gr80211_copy_d2h_async(gr80211_ctx *c, void *h_dst, const void *d_src, size_t bytes, void *stream)

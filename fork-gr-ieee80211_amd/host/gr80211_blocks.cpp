@@ -12,11 +12,17 @@ namespace host {
 
 namespace {
 
-struct stopwatch {  // adds the time it lives to a counter
+struct stopwatch {  // adds the time it lives to a counter; with a name, says so when it lived for more than half a millisecond
     double &acc;
+    const char *slow;
     std::chrono::steady_clock::time_point t0;
-    explicit stopwatch(double &a) : acc(a), t0(std::chrono::steady_clock::now()) {}
-    ~stopwatch() { acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+    explicit stopwatch(double &a, const char *say_if_slow = nullptr) : acc(a), slow(say_if_slow), t0(std::chrono::steady_clock::now()) {}
+    ~stopwatch()
+    {
+        const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        acc += dt;
+        if (slow && dt > 0.0005) fprintf(stderr, "  host held %.2f ms in %s\n", dt * 1e3, slow);
+    }
 };
 
 const int LSIG_SPAN = 224;       // samples from the trigger to the end of L-SIG (lib/signal_impl.cc:110,154)
@@ -99,6 +105,13 @@ bool block::tag_values_at(int port, uint64_t offset, const char *const *keys, do
             if (it->key == keys[k]) out[k] = it->value;
     }
     return any;
+}
+
+uint64_t block::next_tag_offset(int port, uint64_t from, uint64_t end) const
+{
+    const std::deque<tag_t> &tv = d_tags[port];
+    auto it = std::lower_bound(tv.begin(), tv.end(), from, [](const tag_t &t, uint64_t o) { return t.offset < o; });
+    return it != tv.end() && it->offset < end ? it->offset : end;
 }
 
 std::vector<tag_t> block::take_output_tags(int port)
@@ -212,7 +225,12 @@ uint64_t upload_log::settled(uint64_t from)
         if (e.g) {
             // nothing free yet and a copy on its way: wait for it, so that every call consumes something
             const int wait = upto == from ? 1 : 0;
+            const auto t0 = std::chrono::steady_clock::now();
             const int done = e.pull ? gr80211_pull_done(e.g->ctx(), e.id, wait) : gr80211_marker_done(e.g->ctx(), e.id, wait);
+            const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            if (dt > 0.0005 && getenv("GR80211_BLOCK_PROFILE"))
+                fprintf(stderr, "  waited %.2f ms for %s %lld of session %p; %zu entries queued, this one ends at item %llu, enqueued up to %llu\n",
+                        dt * 1e3, e.pull ? "pull" : "marker", e.id, (void *)e.g, d_q.size(), (unsigned long long)e.upto, (unsigned long long)d_enq);
             if (done != 1) break;
         }
         upto = std::max(upto, e.upto);
@@ -228,6 +246,76 @@ bool upload_log::drain()
         if (e.g && (e.pull ? gr80211_pull_done(e.g->ctx(), e.id, 1) : gr80211_marker_done(e.g->ctx(), e.id, 1)) != 1) ok = false;
     d_q.clear();
     return ok;
+}
+
+// ------------------------------------------------------------------------------------ uploader
+uploader::uploader(int device) : d_a(device)
+{
+    if (const char *e = getenv("GR80211_UPLOAD_STREAMS"))
+        if (atoi(e) == 2) d_b.reset(new gpu_session(device));
+    if (const char *e = getenv("GR80211_UPLOAD_SPLIT")) d_firstSplit = atoi(e);  // experiments
+}
+
+bool uploader::send(gpu_session &direct, int n_src, const char *const *src, char *const *dst, size_t items, size_t item,
+                    uint64_t pos0, bool pinned, std::string &err)
+{
+    if (items == 0) return true;
+    if (!pinned) {
+        for (int a = 0; a < n_src; a++)
+            if (gr80211_copy_h2d(direct.ctx(), dst[a], src[a], items * item, nullptr) != GR80211_OK) {
+                err = "upload failed: " + direct.error();
+                return false;
+            }
+        d_log.add(nullptr, 0, pos0 + items);  // an ordinary copy has run when it returns
+        return true;
+    }
+    // Each piece has its own completion: this call's caller consumes the first piece's items and leaves the others on
+    // their way, later calls add what they are newly offered as one more piece and consume what has arrived, so that
+    // copies are queued ahead of the link while the host works.  Only a window that finds nothing on its way is cut
+    // up: then the lag has to be built.
+    const size_t bytes = items * item;
+    size_t pieces = 1;
+    if (d_log.empty())
+        pieces = d_firstSplit > 0 ? (size_t)d_firstSplit : bytes >= ((size_t)4 << 20) ? 8 : bytes >= ((size_t)1 << 20) ? 4 : bytes >= ((size_t)256 << 10) ? 2 : 1;
+    size_t per = items / pieces * item / 64 * 64 / item;  // whole 64-byte lines: the wide form of the copy kernel
+    if (per == 0) pieces = 1;
+    // small pieces go by the kernel that reads host memory itself (a launch, nothing else); from a megabyte on the
+    // runtime's copy engines are as fast and leave the compute units alone
+    static const char *mode = getenv("GR80211_UPLOAD");  // "dma" / "pull": one way for every size (experiments)
+    for (size_t at = 0, k = 0; at < items; k++) {
+        const size_t len = k + 1 < pieces ? per : items - at;
+        const bool use_dma = mode ? mode[0] == 'd' : len * item >= ((size_t)1 << 20);
+        gpu_session &via = (d_nPiece++ & 1) && d_b ? *d_b : d_a;
+        gr80211_ctx *c = via.ctx();
+        long long id = 0;
+        for (int a = 0; a < n_src; a++) {
+            const long long rc = use_dma ? gr80211_copy_h2d_async(c, dst[a] + at * item, src[a] + at * item, len * item, nullptr)
+                                         : gr80211_pull_h2d(c, dst[a] + at * item, src[a] + at * item, len * item, nullptr);
+            if (rc < 0) {
+                err = "upload failed: " + via.error();
+                return false;
+            }
+            id = rc;  // the last source's copy is the last to finish
+        }
+        at += len;
+        if (use_dma) {
+            id = gr80211_marker_record(c, nullptr);
+            if (id < 0) {
+                err = "marker: " + via.error();
+                return false;
+            }
+        }
+        d_log.add(&via, id, pos0 + at, !use_dma);
+    }
+    return true;
+}
+
+bool uploader::join(gr80211_ctx *c)
+{
+    if (d_nPiece == 0) return true;
+    d_nPiece = 0;
+    return gr80211_stream_wait(c, nullptr, d_a.ctx(), nullptr) == GR80211_OK &&
+           (!d_b || gr80211_stream_wait(c, nullptr, d_b->ctx(), nullptr) == GR80211_OK);
 }
 
 // ------------------------------------------------------------------------------------ gpu_session
@@ -368,37 +456,130 @@ decode::sptr decode::make(bool ifdebug, int batch_frames, int device)
 }
 
 decode::decode(bool ifdebug, int batch_frames, int device)
-    : block(1), d_debug(ifdebug), d_batch(batch_frames < 1 ? 1 : batch_frames), d_gpu(device), d_llr(d_gpu, sizeof(float))
+    : block(1), d_debug(ifdebug), d_batch(batch_frames < 1 ? 1 : batch_frames), d_up(device)
 {
-    if (!d_gpu.ok()) d_err = "gr80211_create failed";
+    if (!d_up.ok()) {
+        d_err = "gr80211_create failed";
+        return;
+    }
+    for (round &r : d_round) {
+        r.gpu.reset(new gpu_session(device));
+        if (!r.gpu->ok()) {
+            d_err = "gr80211_create failed";
+            return;
+        }
+    }
+    d_fill = &d_round[0];
+    d_fill->state = round::FILL;
+    if (const char *e = getenv("GR80211_DECODE_MAX_HOLD")) set_max_hold((size_t)atoll(e));  // experiments
+    // the arenas and result buffers of the first two rounds exist before the stream starts (making them takes
+    // milliseconds); the third follows when a stream is fast enough to need it
+    for (int k = 0; k < 2; k++) {
+        round &r = d_round[k];
+        const size_t nf = (size_t)std::min(d_batch, 8192);
+        if (!reserve(r, 1) || !r.gpu->buffer(1, nf * OUT_STRIDE) || !r.gpu->buffer(2, nf * 4) || !r.gpu->buffer(3, nf * 4) ||
+            !r.gpu->staging(0, nf * OUT_STRIDE) || !r.gpu->staging(1, nf * 4)) {
+            d_err = "device memory for the held soft bits exhausted";
+            return;
+        }
+    }
 }
 
-decode::~decode() { unpin_all(); }
+decode::~decode()
+{
+    // nothing of this block may still be on its way when its buffers go
+    d_up.log().drain();
+    if (d_up.ok()) d_up.sync();
+    for (round &r : d_round) {
+        if (!r.gpu || !r.gpu->ok()) continue;
+        r.gpu->sync();
+        if (r.llr) gr80211_dev_free(r.gpu->ctx(), r.llr);
+    }
+    unpin_all();
+}
+
+void decode::set_ampdu_strict(bool on)
+{
+    d_strict = on;
+    for (round &r : d_round)
+        if (r.gpu) r.gpu->set_ampdu_strict(on);
+}
 
 void decode::forecast(int noutput_items, gr_vector_int &ninput_items_required)
 {
     ninput_items_required[0] = noutput_items + 160;  // lib/decode_impl.cc:54-58
 }
 
+bool decode::reserve(round &r, size_t items)
+{
+    if (items <= r.cap) return true;
+    gr80211_ctx *c = r.gpu->ctx();
+    // an arena is made for a whole round at once (what a round may hold, and a window and the longest packet on
+    // top): growing it later means a copy and a wait
+    const size_t cap = std::max<size_t>(std::max<size_t>(2 * r.cap, items), std::min<size_t>(d_maxHold, (size_t)1 << 27) + ((size_t)1 << 22));
+    float *q = static_cast<float *>(gr80211_dev_alloc(c, (cap + 64) * sizeof(float)));
+    if (!q) return false;
+    if (r.n) {
+        // what the arena holds moves over once the copies that are filling it have run
+        if (!d_up.sync() || gr80211_copy_d2d(c, q, r.llr, r.n * sizeof(float), nullptr) != GR80211_OK) {
+            gr80211_dev_free(c, q);
+            return false;
+        }
+    }
+    if (r.llr) gr80211_dev_free(c, r.llr);
+    r.llr = q;
+    r.cap = cap;
+    return true;
+}
+
+// Window items [from, to) go to the round being filled (it holds the stream from its first packet on, gaps and all);
+// a round without a packet holds nothing, so the items are free at once.
+bool decode::send(const float *in, int from, int to)
+{
+    if (to <= from) return true;
+    round &f = *d_fill;
+    const uint64_t r0 = nitems_read(0);
+    if (f.desc.empty()) {
+        d_up.log().add(nullptr, 0, r0 + (uint64_t)to);
+        return true;
+    }
+    const size_t cnt = (size_t)(to - from);
+    if (!reserve(f, f.n + cnt)) {
+        d_err = "device memory for the held soft bits exhausted";
+        return false;
+    }
+    const char *src = reinterpret_cast<const char *>(in + from);
+    char *dst = reinterpret_cast<char *>(f.llr + f.n);
+    if (!d_up.send(*f.gpu, 1, &src, &dst, cnt, sizeof(float), r0 + (uint64_t)from, is_pinned(src, cnt * sizeof(float)), d_err))
+        return false;
+    f.n += cnt;
+    return true;
+}
+
 int decode::general_work(int, gr_vector_int &ninput_items, gr_vector_const_void_star &input_items, gr_vector_void_star &)
 {
+    consume_each(0);
+    if (!d_err.empty()) return 0;
     const float *in = static_cast<const float *>(input_items[0]);
     const int n = ninput_items[0];
-    int used = 0;
+    const uint64_t r0 = nitems_read(0);
+    upload_log &log = d_up.log();
+    if (log.enqueued() < r0) log.set_enqueued(r0);
+    d_nCalls++;
+    // asking the runtime about the rounds in flight costs a few us: not every call
+    if ((d_nCalls & 3) == 0 && !d_flight.empty() && !advance(false, false)) return 0;
+    // items [used, n) of the window are new; the ones before were taken by an earlier call and wait for their copies
+    int used = (int)std::min<uint64_t>(log.enqueued() - r0, (uint64_t)n);
+    int span = used;  // window items from here on have not been sent yet
     std::vector<tag_t> tags;
     while (used < n) {
         if (d_state == S_IDLE) {
-            const uint64_t at = nitems_read(0) + (uint64_t)used;
+            const uint64_t at = r0 + (uint64_t)used;
             get_tags_in_range(tags, 0, at, at + 1);
             if (tags.empty()) {
                 // The reference stays idle until an item carries tags (lib/decode_impl.cc:70-72,125-126);
                 // untagged items between packets are passed over here.
-                get_tags_in_range(tags, 0, at + 1, nitems_read(0) + (uint64_t)n);
-                if (tags.empty()) {
-                    used = n;
-                    break;
-                }
-                used = (int)(tags[0].offset - nitems_read(0));
+                used = (int)(next_tag_offset(0, at + 1, r0 + (uint64_t)n) - r0);
                 continue;
             }
             t_format = (long)tag_value(tags, "format", DEFAULT_TAG);
@@ -435,20 +616,26 @@ int decode::general_work(int, gr_vector_int &ninput_items, gr_vector_const_void_
                     }
                 }
                 m.len = nbytes + 3;
-                if (d_desc.empty()) {
+                if (d_flight.empty() && d_fill->desc.empty() && d_fill->ready.empty()) {
                     message_port_pub("out", m);
                 } else {
                     // packets before it are still waiting for the GPU: it takes its turn behind them
-                    d_ready.emplace_back(d_desc.size(), std::move(m));
+                    d_fill->ready.emplace_back(d_fill->desc.size(), std::move(m));
                 }
                 d_nPdu++;
             } else {
                 d_state = S_COLLECT;
-            }
-            if (d_state == S_COLLECT) {
+                round &f = *d_fill;
+                if (f.desc.empty()) {
+                    // the round's first packet: the round holds the stream from here on
+                    if (!send(in, span, used)) return 0;
+                    span = used;
+                    f.base = at;
+                    f.n = 0;
+                }
                 gr80211_dec_desc d;
                 memset(&d, 0, sizeof(d));
-                d.llr_off = (int64_t)d_llr.size();
+                d.llr_off = (int64_t)(at - f.base);
                 d.n_llr = (int32_t)t_nTotal;
                 d.format = (int32_t)t_format;
                 d.len = (int32_t)t_len;
@@ -456,86 +643,140 @@ int decode::general_work(int, gr_vector_int &ninput_items, gr_vector_const_void_
                 d.mcs = (int32_t)t_mcs;
                 d.ampdu = (int32_t)t_ampdu;
                 d.trellis = (int32_t)v_trellis;
-                d_desc.push_back(d);
+                f.desc.push_back(d);
             }
         }
         if (d_state == S_COLLECT || d_state == S_CLEAN) {
             const long need = t_nTotal - t_nProcd;
             const int take = (int)std::min<long>(need < 0 ? 0 : need, n - used);
-            if (d_state == S_COLLECT && !d_llr.append(in + used, (size_t)take)) {
-                d_err = "upload of the soft bits failed: " + d_gpu.error();
-                consume_each(used);
-                return 0;
-            }
             t_nProcd += take;
             used += take;
             if (t_nProcd >= t_nTotal) {
                 const bool collected = d_state == S_COLLECT;
                 d_state = S_IDLE;
-                if (collected && (int)d_desc.size() >= d_batch && !run_batch()) {
-                    consume_each(used);
-                    return 0;
+                round &f = *d_fill;
+                if (collected && ((int)f.desc.size() >= d_batch || f.n + (size_t)(used - span) >= d_maxHold)) {
+                    // the round ends with this packet
+                    if (!send(in, span, used)) return 0;
+                    span = used;
+                    if (!cut()) return 0;
                 }
             }
         }
     }
-    consume_each(used);
+    if (!send(in, span, n)) return 0;
+    log.set_enqueued(r0 + (uint64_t)n);
+    consume_each((int)(log.settled(r0) - r0));
     return 0;
+}
+
+// The round being filled goes to the decoder (descriptors, kernels and the copies of the results back are put on its
+// stream, nothing is waited for); the packets that follow fill another round.
+bool decode::cut()
+{
+    round &r = *d_fill;
+    gr80211_ctx *c = r.gpu->ctx();
+    const int nf = (int)r.desc.size();
+    // the soft bits came by streams of their own
+    if (!d_up.join(c)) {
+        d_err = r.gpu->error();
+        return false;
+    }
+    uint8_t *dout = static_cast<uint8_t *>(r.gpu->buffer(1, (size_t)nf * OUT_STRIDE));
+    int32_t *dlen = static_cast<int32_t *>(r.gpu->buffer(2, (size_t)nf * 4));
+    int32_t *dnp = static_cast<int32_t *>(r.gpu->buffer(3, (size_t)nf * 4));
+    uint8_t *out = static_cast<uint8_t *>(r.gpu->staging(0, (size_t)nf * OUT_STRIDE));
+    int32_t *len = static_cast<int32_t *>(r.gpu->staging(1, (size_t)nf * 4));
+    if (!dout || !dlen || !dnp || !out || !len) {
+        d_err = "allocation of the output buffers failed";
+        return false;
+    }
+    if (gr80211_decode_batch(c, r.llr, r.n, r.desc.data(), nf, 0, dout, OUT_STRIDE, dlen, dnp, nullptr, 0, nullptr) != GR80211_OK ||
+        gr80211_push_d2h(c, len, dlen, (size_t)nf * 4, nullptr) != GR80211_OK ||
+        gr80211_push_d2h(c, out, dout, (size_t)nf * OUT_STRIDE, nullptr) != GR80211_OK) {
+        d_err = r.gpu->error();
+        return false;
+    }
+    r.state = round::DECODE;
+    d_flight.push_back(&r);
+    d_nRounds++;
+    round *nx = nullptr;
+    while (!nx) {
+        for (round &q : d_round)
+            if (q.state == round::FREE) nx = &q;
+        if (!nx && !advance(true, false)) return false;  // the oldest round in flight gives its place
+    }
+    nx->n = 0;
+    nx->desc.clear();
+    nx->ready.clear();
+    nx->state = round::FILL;
+    d_fill = nx;
+    return true;
+}
+
+void decode::publish_ready(round &r, size_t upto_desc, size_t &at)
+{
+    for (; at < r.ready.size() && r.ready[at].first <= upto_desc; at++) message_port_pub("out", r.ready[at].second);
+}
+
+// The oldest rounds in flight are published as their streams run dry.  wait_front: wait for the oldest one;
+// wait_all: for all.
+bool decode::advance(bool wait_front, bool wait_all)
+{
+    while (!d_flight.empty()) {
+        round *r = d_flight.front();
+        if (!r->gpu->idle()) {
+            if (!(wait_front || wait_all)) break;
+            if (!r->gpu->sync()) {
+                d_err = r->gpu->error();
+                return false;
+            }
+        }
+        if (gr80211_last_batch_refused(r->gpu->ctx()) != 0) {
+            d_err = "the GPU refused a batch: the descriptors on the host do not describe it";
+            return false;
+        }
+        const int nf = (int)r->desc.size();
+        const uint8_t *out = static_cast<const uint8_t *>(r->gpu->staging(0, (size_t)nf * OUT_STRIDE));
+        const int32_t *len = static_cast<const int32_t *>(r->gpu->staging(1, (size_t)nf * 4));
+        size_t at = 0;
+        for (int i = 0; i < nf; i++) {
+            publish_ready(*r, (size_t)i, at);
+            d_nPdu += publish_slots(out + (size_t)i * OUT_STRIDE, len + i, 1, OUT_STRIDE);
+        }
+        publish_ready(*r, (size_t)nf, at);
+        r->ready.clear();
+        r->desc.clear();
+        r->n = 0;
+        r->state = round::FREE;
+        d_flight.pop_front();
+        wait_front = false;  // only the oldest is waited for
+    }
+    // channel messages that waited for rounds in flight only
+    if (d_flight.empty() && d_fill && d_fill->desc.empty() && !d_fill->ready.empty()) {
+        size_t at = 0;
+        publish_ready(*d_fill, 0, at);
+        d_fill->ready.clear();
+    }
+    return true;
 }
 
 bool decode::flush()
 {
+    if (!d_err.empty()) return false;
+    if (!d_up.log().drain()) {
+        d_err = "upload of the soft bits failed";
+        return false;
+    }
     // a packet cut off by the end of the stream is dropped, as the reference never finishes it either
-    if (d_state == S_COLLECT && !d_desc.empty()) {
-        d_llr.truncate((size_t)d_desc.back().llr_off);
-        d_desc.pop_back();
-    }
+    if (d_state == S_COLLECT && !d_fill->desc.empty()) d_fill->desc.pop_back();
     d_state = S_IDLE;
-    return run_batch();
-}
-
-bool decode::run_batch()
-{
-    // called between packets only: every pending descriptor has all of its soft bits
-    const int n = (int)d_desc.size();
-    if (n <= 0) {
-        for (auto &r : d_ready) message_port_pub("out", r.second);
-        d_ready.clear();
-        return true;
-    }
-    if (!d_gpu.ok()) return false;
-    const size_t nfl = d_llr.size();
-    const void *dl = d_llr.data();  // uploaded window by window as the stream came in
-    uint8_t *dout = static_cast<uint8_t *>(d_gpu.buffer(1, (size_t)n * OUT_STRIDE));
-    int32_t *dlen = static_cast<int32_t *>(d_gpu.buffer(2, (size_t)n * 4));
-    int32_t *dnp = static_cast<int32_t *>(d_gpu.buffer(3, (size_t)n * 4));
-    if (!dl || !dout || !dlen || !dnp) {
-        d_err = "device allocation failed";
-        return false;
-    }
-    gr80211_ctx *c = d_gpu.ctx();
-    uint8_t *out = static_cast<uint8_t *>(d_gpu.staging(0, (size_t)n * OUT_STRIDE));
-    int32_t *len = static_cast<int32_t *>(d_gpu.staging(1, (size_t)n * 4));
-    if (!out || !len) {
-        d_err = "page-locked host memory exhausted";
-        return false;
-    }
-    if (gr80211_decode_batch(c, static_cast<const float *>(dl), nfl, d_desc.data(), n, 0, dout, OUT_STRIDE, dlen, dnp,
-                             nullptr, 0, nullptr) != GR80211_OK ||
-        gr80211_copy_d2h(c, len, dlen, (size_t)n * 4, nullptr) != GR80211_OK ||
-        gr80211_copy_d2h(c, out, dout, (size_t)n * OUT_STRIDE, nullptr) != GR80211_OK) {
-        d_err = d_gpu.error();
-        return false;
-    }
-    size_t r = 0;
-    for (int i = 0; i < n; i++) {
-        for (; r < d_ready.size() && d_ready[r].first <= (size_t)i; r++) message_port_pub("out", d_ready[r].second);
-        d_nPdu += publish_slots(out + (size_t)i * OUT_STRIDE, len + i, 1, OUT_STRIDE);
-    }
-    for (; r < d_ready.size(); r++) message_port_pub("out", d_ready[r].second);
-    d_ready.clear();
-    d_llr.clear();
-    d_desc.clear();
+    if (!d_fill->desc.empty() && !cut()) return false;
+    if (!advance(true, true)) return false;
+    size_t at = 0;
+    publish_ready(*d_fill, d_fill->desc.size(), at);
+    d_fill->ready.clear();
+    d_fill->n = 0;
     return true;
 }
 
@@ -550,10 +791,10 @@ const size_t MAX_SPAN = 224 + 80 * ((4095 * 8 + 22 + 23) / 24);
 rx::sptr rx::make(int n_rx, int batch_frames, int device) { return sptr(new rx(n_rx, batch_frames, device)); }
 
 rx::rx(int n_rx, int batch_frames, int device, int n_out)
-    : block(n_rx == 2 ? 3 : 2, n_out), d_nrx(n_rx == 2 ? 2 : 1), d_batch(batch_frames < 1 ? 1 : batch_frames), d_gpu(device),
-      d_gpu2(device), d_maxHold((size_t)1 << 24)
+    : block(n_rx == 2 ? 3 : 2, n_out), d_nrx(n_rx == 2 ? 2 : 1), d_batch(batch_frames < 1 ? 1 : batch_frames), d_up(device),
+      d_maxHold((size_t)1 << 24)
 {
-    if (!d_gpu.ok() || !d_gpu2.ok()) {
+    if (!d_up.ok()) {
         d_err = "gr80211_create failed";
         return;
     }
@@ -568,7 +809,6 @@ rx::rx(int n_rx, int batch_frames, int device, int n_out)
     d_fill->state = round::FILL;
     if (const char *e = getenv("GR80211_RX_MAX_HOLD")) set_max_hold((size_t)atoll(e));  // experiments
     d_profile = getenv("GR80211_BLOCK_PROFILE") != nullptr;
-    if (const char *e = getenv("GR80211_RX_SPLIT")) d_firstSplit = atoi(e);  // experiments
     // the arenas of the first two rounds exist before the stream starts (making one takes milliseconds); the others
     // follow when a stream is fast enough to need them
     for (int k = 0; k < 2; k++) {
@@ -590,9 +830,8 @@ rx::~rx()
                         "(of which cut %.4f publish %.4f)\n", (unsigned long long)d_nCalls, (unsigned long long)d_nRounds,
                 d_tScan, d_tUpload, d_tSettle, d_tAdvance, d_tCut, d_tPublish);
     // nothing of this block may still be on its way when its buffers go
-    d_up.drain();
-    if (d_gpu.ok()) d_gpu.sync();
-    if (d_gpu2.ok()) d_gpu2.sync();
+    d_up.log().drain();
+    if (d_up.ok()) d_up.sync();
     for (round &r : d_round) {
         if (!r.gpu || !r.gpu->ok()) continue;
         r.gpu->sync();
@@ -605,7 +844,6 @@ rx::~rx()
 void rx::set_ampdu_strict(bool on)
 {
     d_strict = on;
-    d_gpu.set_ampdu_strict(on);
     for (round &r : d_round)
         if (r.gpu) r.gpu->set_ampdu_strict(on);
 }
@@ -635,7 +873,7 @@ bool rx::reserve(round &r, size_t items)
         char *q = static_cast<char *>(gr80211_dev_alloc(c, (cap + 64) * sizeof(gr_complex)));
         if (!q) return false;
         // what the arena holds moves over once the copies that are filling it have run
-        if (r.n && !(d_gpu.sync() && d_gpu2.sync())) return false;
+        if (r.n && !d_up.sync()) return false;
         if (r.n && gr80211_copy_d2d_async(c, q, r.iq[a], r.n * sizeof(gr_complex), nullptr) != GR80211_OK) return false;
         if (r.iq[a]) {
             if (!r.gpu->sync()) return false;
@@ -666,19 +904,20 @@ int rx::take_input(gr_vector_int &ninput_items, gr_vector_const_void_star &input
     int n = std::min(ninput_items[0], ninput_items[1]);
     if (d_nrx == 2) n = std::min(n, ninput_items[2]);
     const uint64_t r0 = nitems_read(0);
-    if (d_up.enqueued() < r0) d_up.set_enqueued(r0);
+    upload_log &log = d_up.log();
+    if (log.enqueued() < r0) log.set_enqueued(r0);
     d_nCalls++;
     if ((d_nCalls & 3) == 0 && !d_flight.empty()) {  // asking the runtime about the rounds in flight costs a few us: not every call
-        stopwatch sw(d_tAdvance);
+        stopwatch sw(d_tAdvance, d_profile ? "advance" : nullptr);
         if (!advance(false, false)) return -1;
     }
     // items [lo, n) of the window are new; the ones before were taken by an earlier call and wait for their copies
-    const int lo = (int)std::min<uint64_t>(d_up.enqueued() - r0, (uint64_t)n);
+    const int lo = (int)std::min<uint64_t>(log.enqueued() - r0, (uint64_t)n);
     if (lo < n) {
         round &f = *d_fill;
         std::vector<tag_t> tags;
         const size_t trig_before = f.trig.size();
-        stopwatch *sw_scan = new stopwatch(d_tScan);
+        stopwatch *sw_scan = new stopwatch(d_tScan, d_profile ? "scan" : nullptr);
         static const char *const keys[3] = {"rad", "snr", "rssi"};
         for (int i = next_set(sync, lo, n); i < n; i = next_set(sync, i + 1, n)) {
             const uint64_t at = r0 + (uint64_t)i;
@@ -694,7 +933,7 @@ int rx::take_input(gr_vector_int &ninput_items, gr_vector_const_void_star &input
         }
         f.n_new += f.trig.size() - trig_before;
         delete sw_scan;
-        stopwatch sw_up(d_tUpload);
+        stopwatch sw_up(d_tUpload, d_profile ? "upload" : nullptr);
         // samples are only held from the first pending sync byte on
         int from = lo;
         if (f.n == 0) {
@@ -712,68 +951,32 @@ int rx::take_input(gr_vector_int &ninput_items, gr_vector_const_void_star &input
                 d_err = "device memory for the held samples exhausted";
                 return -1;
             }
-            if (from > lo) d_up.add(nullptr, 0, r0 + (uint64_t)from);  // items passed over need no copy
+            if (from > lo) log.add(nullptr, 0, r0 + (uint64_t)from);  // items passed over need no copy
             bool pinned = true;
-            for (int a = 0; a < d_nrx; a++)
-                pinned = pinned && is_pinned(static_cast<const gr_complex *>(input_items[1 + a]) + from, cnt * sizeof(gr_complex));
-            // Page-locked windows travel in pieces, each with its own completion: this call consumes the first piece's
-            // items and leaves the others on their way, later calls add what they are newly offered as one more piece
-            // and consume what has arrived, so that copies are queued ahead of the link while the host works.  Only a
-            // window that finds nothing on its way is cut up: then the lag has to be built.
-            size_t pieces = 1;
-            if (pinned && d_up.empty()) pieces = d_firstSplit ? (size_t)d_firstSplit : cnt >= ((size_t)1 << 19) ? 8 : cnt >= ((size_t)1 << 17) ? 4 : cnt >= 32768 ? 2 : 1;
-            const size_t half = (cnt / pieces) & ~(size_t)1;
-            // small pieces go by the kernel that reads host memory itself (a launch, nothing else); from a megabyte on
-            // the runtime's copy engines are faster and do not share the compute units with the decoders
-            static const char *mode = getenv("GR80211_UPLOAD");  // "dma" / "pull": one way for every size (experiments)
-            for (size_t at = 0, k = 0; at < cnt; k++) {
-                const size_t len = k + 1 < pieces ? half : cnt - at;
-                const bool use_dma = mode ? mode[0] == 'd' : len * sizeof(gr_complex) >= ((size_t)1 << 20);
-                long long id = 0;
-                // asynchronous copies alternate between the block's two upload streams
-                gpu_session *via = !pinned ? f.gpu.get() : (d_nPiece++ & 1) ? &d_gpu2 : &d_gpu;
-                gr80211_ctx *c = via->ctx();
-                for (int a = 0; a < d_nrx; a++) {
-                    const gr_complex *src = static_cast<const gr_complex *>(input_items[1 + a]) + from + at;
-                    char *dst = f.iq[a] + (f.n + at) * sizeof(gr_complex);
-                    const long long rc = !pinned ? gr80211_copy_h2d(c, dst, src, len * sizeof(gr_complex), nullptr)
-                                         : use_dma ? gr80211_copy_h2d_async(c, dst, src, len * sizeof(gr_complex), nullptr)
-                                                   : gr80211_pull_h2d(c, dst, src, len * sizeof(gr_complex), nullptr);
-                    if (rc < 0) {
-                        d_err = "upload of the samples failed: " + f.gpu->error();
-                        return -1;
-                    }
-                    id = rc;  // the last antenna's copy is the last to finish
-                }
-                at += len;
-                if (pinned && use_dma) {
-                    id = gr80211_marker_record(c, nullptr);
-                    if (id < 0) {
-                        d_err = "marker: " + f.gpu->error();
-                        return -1;
-                    }
-                }
-                if (pinned)
-                    d_up.add(via, id, r0 + (uint64_t)from + at, !use_dma);
-                else
-                    d_up.add(nullptr, 0, r0 + (uint64_t)from + at);  // an ordinary copy has run when it returns
+            const char *src[2];
+            char *dst[2];
+            for (int a = 0; a < d_nrx; a++) {
+                src[a] = reinterpret_cast<const char *>(static_cast<const gr_complex *>(input_items[1 + a]) + from);
+                dst[a] = f.iq[a] + f.n * sizeof(gr_complex);
+                pinned = pinned && is_pinned(src[a], cnt * sizeof(gr_complex));
             }
+            if (!d_up.send(*f.gpu, d_nrx, src, dst, cnt, sizeof(gr_complex), r0 + (uint64_t)from, pinned, d_err)) return -1;
             f.n += cnt;
         } else {
-            d_up.add(nullptr, 0, r0 + (uint64_t)n);
+            log.add(nullptr, 0, r0 + (uint64_t)n);
         }
-        d_up.set_enqueued(r0 + (uint64_t)n);
+        log.set_enqueued(r0 + (uint64_t)n);
         // a round is cut when enough sync bytes are pending (the frame a round carried over counts once its samples
         // have come in), or when it holds as many samples as it may
         const uint64_t end = f.base + f.n;
         const bool enough = f.trig.size() >= (size_t)d_batch && (f.n_new > 0 || (d_wantEnd && end >= d_wantEnd));
         if (f.n > 0 && (enough || f.n >= d_maxHold)) {
-            stopwatch sw_cut(d_tCut);
+            stopwatch sw_cut(d_tCut, d_profile ? "cut" : nullptr);
             if (!cut(false)) return -1;
         }
     }
-    stopwatch sw_settle(d_tSettle);
-    const uint64_t upto = d_up.settled(r0);
+    stopwatch sw_settle(d_tSettle, d_profile ? "settle" : nullptr);
+    const uint64_t upto = log.settled(r0);
     return (int)(upto - r0);
 }
 
@@ -785,13 +988,11 @@ bool rx::cut(bool final)
     gr80211_ctx *c = r.gpu->ctx();
     const uint64_t end = r.base + r.n;
     r.final = final;
-    // whatever the round's stream does from here on comes after the uploads, which went by the block's two streams
-    if (d_nPiece && (gr80211_stream_wait(c, nullptr, d_gpu.ctx(), nullptr) != GR80211_OK ||
-                     gr80211_stream_wait(c, nullptr, d_gpu2.ctx(), nullptr) != GR80211_OK)) {
+    // whatever the round's stream does from here on comes after the uploads, which went by streams of their own
+    if (!d_up.join(c)) {
         d_err = r.gpu->error();
         return false;
     }
-    d_nPiece = 0;
     round *nx = nullptr;
     if (!final) {
         nx = free_round();
@@ -861,6 +1062,7 @@ bool rx::cut(bool final)
     }
     r.state = round::PROBE;
     r.t_cut = now();
+    if (d_profile) fprintf(stderr, "  cut of round %d at item %llu (%.4f s)\n", (int)(&r - d_round), (unsigned long long)end, r.t_cut);
     d_flight.push_back(&r);
     d_nRounds++;
     d_fill = nx;
@@ -962,7 +1164,7 @@ bool rx::advance(bool wait_front, bool wait_all)
 bool rx::flush()
 {
     if (!d_err.empty()) return false;
-    if (!d_up.drain()) {
+    if (!d_up.log().drain()) {
         d_err = "upload of the samples failed";
         return false;
     }
@@ -997,8 +1199,8 @@ bool rx::start_frames(round &r)
     }
     if (gr80211_rx_resume(c, r.iq[0], d_nrx == 2 ? r.iq[1] : nullptr, r.n, r.fd.data(), r.fidx.data(), r.info, nf, dout,
                           OUT_STRIDE, dlen, dnp, nullptr, nullptr) != GR80211_OK ||
-        gr80211_copy_d2h_async(c, len, dlen, (size_t)nf * 4, nullptr) != GR80211_OK ||
-        gr80211_copy_d2h_async(c, out, dout, (size_t)nf * OUT_STRIDE, nullptr) != GR80211_OK) {
+        gr80211_push_d2h(c, len, dlen, (size_t)nf * 4, nullptr) != GR80211_OK ||
+        gr80211_push_d2h(c, out, dout, (size_t)nf * OUT_STRIDE, nullptr) != GR80211_OK) {
         d_err = r.gpu->error();
         return false;
     }

@@ -99,6 +99,8 @@ protected:
     // The values of the tags `keys` on item `offset` of `port` (the last tag of a key wins, as pmt::dict_add overwrites)
     // without copying tags; false if the item carries no tag at all.  out[k] keeps its value where key k is missing.
     bool tag_values_at(int port, uint64_t offset, const char *const *keys, double *out, int n_keys) const;
+    // offset of the first tag of `port` at or after `from`, or `end` if there is none before it
+    uint64_t next_tag_offset(int port, uint64_t from, uint64_t end) const;
     void message_port_pub(const std::string &port, const pdu_t &m);
     // Publishes the messages n frame slots hold (stride bytes apart, len[i] bytes used); returns how many.
     uint64_t publish_slots(const uint8_t *out, const int32_t *len, int n, int stride);
@@ -172,6 +174,38 @@ private:
     uint64_t d_enq = 0;
 };
 
+// The way of a block's input windows to the GPU.  A window in page-locked memory is cut into pieces that travel by a
+// stream of their own, so that none queues behind a decoder; every piece has an entry in the log, and general_work
+// consumes the items whose pieces have arrived.  Pieces below a megabyte go by gr80211_pull_h2d, larger ones by the
+// runtime's copy engines.  Windows in ordinary memory are copied before send() returns, by the context the caller
+// names.  One upload stream and one stream per round in flight is what a process has hardware queues for (four, of
+// which the runtime keeps one for the default stream): streams that share a queue run one after the other, and a
+// decoder ahead in the queue holds up whatever follows.  GR80211_UPLOAD_STREAMS=2 sends every other piece by a second
+// stream (for a process that has been given more queues).
+class uploader
+{
+public:
+    explicit uploader(int device);
+    bool ok() const { return d_a.ok() && (!d_b || d_b->ok()); }
+    gpu_session &session() { return d_a; }
+    upload_log &log() { return d_log; }
+    // `items` items of `item` bytes from each of n_src sources (parallel streams: item k of all of them has stream
+    // position pos0 + k) to dst[0..n_src).  false on an error (text in err).
+    bool send(gpu_session &direct, int n_src, const char *const *src, char *const *dst, size_t items, size_t item,
+              uint64_t pos0, bool pinned, std::string &err);
+    // what c's stream is given from now on runs after every piece sent so far
+    bool join(gr80211_ctx *c);
+    bool sync() { return d_a.sync() && (!d_b || d_b->sync()); }  // every piece sent so far has arrived
+    void set_first_split(int pieces) { d_firstSplit = pieces; }
+
+private:
+    gpu_session d_a;
+    std::unique_ptr<gpu_session> d_b;  // the second stream, if asked for
+    upload_log d_log;
+    unsigned d_nPiece = 0;  // pieces since the last join
+    int d_firstSplit = 0;   // pieces a window that finds nothing on its way is cut into (0: by its size)
+};
+
 // Items waiting for the GPU, kept in device memory: every window of the stream is uploaded when it arrives, so the
 // host holds no copy.  Append at the back, release at the front.
 class device_fifo
@@ -233,29 +267,51 @@ public:
                      gr_vector_void_star &output_items) override;
     bool flush() override;
 
-    void set_ampdu_strict(bool on) { d_gpu.set_ampdu_strict(on); }
+    void set_ampdu_strict(bool on);
+    // soft bits a round holds at most before it is cut (at the next packet boundary) whatever the packet count
+    void set_max_hold(size_t items) { d_maxHold = items < 4096 ? 4096 : items; }
     uint64_t packets_seen() const { return d_nSeen; }
     uint64_t pdus_published() const { return d_nPdu; }
+    uint64_t rounds_cut() const { return d_nRounds; }
 
 protected:
-    gr80211_ctx *pin_context() override { return d_gpu.ctx(); }
+    gr80211_ctx *pin_context() override { return d_up.session().ctx(); }
 
 private:
     decode(bool ifdebug, int batch_frames, int device);
-    bool run_batch();
+    // One stretch of the stream on its way through the GPU: its soft bits as they came (packets back to back, whatever
+    // lies between them included), a descriptor per packet.  While one round is filled, the ones before it decode on
+    // the streams of their own contexts and are published in order.
+    struct round {
+        std::unique_ptr<gpu_session> gpu;
+        float *llr = nullptr;              // device arena
+        size_t cap = 0, n = 0;             // soft bits it can hold / holds
+        uint64_t base = 0;                 // absolute index of item 0
+        std::vector<gr80211_dec_desc> desc;
+        std::vector<std::pair<size_t, pdu_t>> ready;  // channel messages of sounding packets and how many packets of
+                                                      // the round precede each
+        enum { FREE, FILL, DECODE } state = FREE;
+    };
+    bool reserve(round &r, size_t items);
+    bool send(const float *in, int from, int to);  // window items [from, to) to the round being filled
+    bool cut();                                    // the round being filled goes to the decoder; another one is filled
+    bool advance(bool wait_front, bool wait_all);
+    void publish_ready(round &r, size_t upto_desc, size_t &at);
 
     bool d_debug;
     int d_batch;
-    gpu_session d_gpu;
+    uploader d_up;
+    static constexpr int N_ROUNDS = 3;
+    round d_round[N_ROUNDS];
+    round *d_fill = nullptr;
+    std::deque<round *> d_flight;
+    size_t d_maxHold = (size_t)1 << 25;
+    bool d_strict = false;
     enum { S_IDLE, S_COLLECT, S_CLEAN } d_state = S_IDLE;
     // tags of the packet being collected (lib/decode_impl.cc:77-88)
     long t_format = 0, t_len = 0, t_nTotal = 0, t_cr = 0, t_mcs = 0, t_ampdu = 0, v_trellis = 0;
     long t_nProcd = 0;
-    device_fifo d_llr;                        // soft bits of the pending packets, back to back
-    std::vector<gr80211_dec_desc> d_desc;     // one per pending packet
-    std::vector<std::pair<size_t, pdu_t>> d_ready;  // channel messages of sounding packets and how many pending
-                                                    // packets precede each
-    uint64_t d_nSeen = 0, d_nPdu = 0;
+    uint64_t d_nSeen = 0, d_nPdu = 0, d_nRounds = 0, d_nCalls = 0;
 };
 
 class rx : public block
@@ -283,7 +339,7 @@ public:
 
 protected:
     rx(int n_rx, int batch_frames, int device, int n_out = 0);
-    gr80211_ctx *pin_context() override { return d_gpu.ctx(); }
+    gr80211_ctx *pin_context() override { return d_up.session().ctx(); }
     struct frame_ref {
         uint64_t pos;  // absolute item index of the trigger byte
         int mcs, len, nsamp;
@@ -326,16 +382,11 @@ protected:
 
     int d_nrx, d_batch;
     int d_muPos = 0;
-    gpu_session d_gpu;                  // page-locking, options; its stream carries every other upload
-    gpu_session d_gpu2;                 // the stream of the uploads in between: two pieces are on the link at a time, and
-                                        // none of them queues behind a round's decoder
-    unsigned d_nPiece = 0;              // uploads since the last cut
-    int d_firstSplit = 0;               // pieces a window that finds nothing on its way is cut into (0: by its size)
-    static constexpr int N_ROUNDS = 4;
+    uploader d_up;                      // the samples' way to the arenas of the round being filled
+    static constexpr int N_ROUNDS = 3;
     round d_round[N_ROUNDS];
     round *d_fill = nullptr;
     std::deque<round *> d_flight;       // rounds being probed / decoded, oldest first
-    upload_log d_up;
     uint64_t d_cursor = 0;              // absolute index where the trigger search resumes (lib/signal_impl.cc:75-106)
     uint64_t d_wantEnd = 0;             // stream position at which the oldest carried-over frame is complete (0: none known)
     size_t d_maxHold;

@@ -72,7 +72,7 @@ EXPORTS = [
     "gr80211_version", "gr80211_table_checksum", "gr80211_tx_samples", "gr80211_tx_batch", "gr80211_set_mu_pos", "gr80211_set_ampdu_strict", "gr80211_tx_mu_batch",
     "gr80211_host_alloc", "gr80211_host_free", "gr80211_copy_d2d", "gr80211_signal_emit_batch", "gr80211_demod_tagged_batch",
     "gr80211_rx_submit", "gr80211_rx_finish", "gr80211_decode_batch_noalloc", "gr80211_rx_resume",
-    "gr80211_last_batch_refused", "gr80211_copy_h2d_async", "gr80211_copy_d2h_async", "gr80211_copy_d2d_async", "gr80211_pull_h2d", "gr80211_pull_done",
+    "gr80211_last_batch_refused", "gr80211_copy_h2d_async", "gr80211_copy_d2h_async", "gr80211_copy_d2d_async", "gr80211_pull_h2d", "gr80211_pull_done", "gr80211_push_d2h",
     "gr80211_stream_idle", "gr80211_stream_wait", "gr80211_marker_record", "gr80211_marker_done",
     "gr80211_host_register", "gr80211_host_unregister",
 ]
@@ -114,6 +114,7 @@ def load_library():
         getattr(L, name).argtypes = [vp, vp, vp, C.c_size_t, vp]
     L.gr80211_pull_h2d.restype = C.c_longlong
     L.gr80211_pull_done.argtypes = [vp, C.c_longlong, C.c_int]
+    L.gr80211_push_d2h.argtypes = [vp, vp, vp, C.c_size_t, vp]
     L.gr80211_stream_idle.argtypes = [vp, vp]
     L.gr80211_stream_wait.argtypes = [vp, vp, vp, vp]
     L.gr80211_marker_record.argtypes = [vp, vp]

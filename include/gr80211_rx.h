@@ -281,6 +281,10 @@ int gr80211_demod_batch(gr80211_ctx *ctx, const void *d_iq0, const void *d_iq1, 
  * vstb_update / vstb_end / descramble / packetAssemble (lib/decode_impl.cc:60-520).
  * d_bits (nullable): n_frames slots of bits_stride bytes receiving the descrambled bit array
  * v_unCodedBits packed LSB-first (bit t of the frame at byte t/8, bit t%8).
+ * With the descriptors on the host the call waits for nothing: the work buffers are sized from the descriptors, the
+ * descriptors travel through page-locked memory of the context (the caller's array is free on return), and the
+ * results are ready when the stream has run what the call gave it.  With GR80211_FLAG_DESC_ON_DEVICE the call waits
+ * once, for the scheduler's totals.
  */
 int gr80211_decode_batch(gr80211_ctx *ctx, const float *d_llr, uint64_t llr_floats,
                          const gr80211_dec_desc *desc, int n_frames, unsigned flags,
@@ -378,6 +382,12 @@ int gr80211_copy_d2d(gr80211_ctx *ctx, void *d_dst, const void *d_src, size_t by
  *   gr80211_pull_done      1 if copy `number` has read all of its source (the source may be overwritten), 0 if not;
  *                          wait != 0: spin until it has.  Numbers arrive in order when a context's pulls all go to one
  *                          stream; the destination is ready for work enqueued on that stream after the pull, as usual.
+ *   gr80211_push_d2h       device-to-host copy done by a kernel that writes page-locked host memory over the link; the
+ *                          data is there when the stream has passed it (gr80211_stream_idle, a marker, gr80211_sync).
+ *                          For results that follow a long kernel: the runtime's copy engines take their copies in the
+ *                          order they were handed over, so a copy that waits for a decoder holds back the uploads of
+ *                          other streams handed over after it (measured: every upload stood still for the length of
+ *                          the decoder); a kernel does not.
  *   gr80211_stream_idle    1 if the stream has run everything enqueued on it, 0 if not (no wait).
  *   gr80211_stream_wait    work enqueued on (ctx, stream) from now on starts after what (other, other_stream) holds now.
  *   gr80211_marker_record  marks the current end of the stream's queue; returns the marker's number (>= 0).
@@ -389,6 +399,7 @@ int gr80211_copy_d2d(gr80211_ctx *ctx, void *d_dst, const void *d_src, size_t by
 int gr80211_copy_h2d_async(gr80211_ctx *ctx, void *d_dst, const void *h_src, size_t bytes, void *stream);
 long long gr80211_pull_h2d(gr80211_ctx *ctx, void *d_dst, const void *h_src, size_t bytes, void *stream);
 int gr80211_pull_done(gr80211_ctx *ctx, long long number, int wait);
+int gr80211_push_d2h(gr80211_ctx *ctx, void *h_dst, const void *d_src, size_t bytes, void *stream);
 int gr80211_copy_d2h_async(gr80211_ctx *ctx, void *h_dst, const void *d_src, size_t bytes, void *stream);
 int gr80211_copy_d2d_async(gr80211_ctx *ctx, void *d_dst, const void *d_src, size_t bytes, void *stream); /* no overlap */
 int gr80211_stream_idle(gr80211_ctx *ctx, void *stream);

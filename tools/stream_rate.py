@@ -48,8 +48,10 @@ def main():
     with open(f_tr, "w") as fh:
         for p in sync.tolist():
             fh.write("%d 0.0 30.0 -40.0\n" % p)
-    # the soft bits `demod` would hand to `decode`, with the tags of each packet's first item
-    info, llr = ctx.demod_batch(iq_t, None, ctx.make_desc(sync, navail), n)
+    # the soft bits `demod` would hand to `decode`, with the tags of each packet's first item (of the first 60000
+    # frames at most: a soft bit takes twice the bytes of the sample it came from)
+    n_all, n = n, min(n, 60000)
+    info, llr = ctx.demod_batch(iq_t[: n * L + 64], None, ctx.make_desc(sync[:n], navail[:n]), n)
     f_llr = os.path.join(work, "llr.bin")
     np.asarray(llr).astype(np.float32).tofile(f_llr)
     f_tg = os.path.join(work, "tags.txt")
@@ -61,17 +63,20 @@ def main():
     ctx.close()
     del arenas, iq_t
     torch.cuda.empty_cache()
+    ns_dec = n * L
+    n = n_all
     ns = n * L
-    print("%d VHT MCS8 frames, %d samples per antenna, %.0f MB of IQ" % (n, ns, ns * 8 / 1e6), flush=True)
+    print("%d VHT MCS8 frames, %d samples per antenna, %.0f MB of IQ; %d of them as soft bits, %.0f MB" %
+          (n, ns, ns * 8 / 1e6, ns_dec // L, os.path.getsize(f_llr) / 1e6), flush=True)
     for pin in (True, False):
-        for chunk, batch in ((8192, 4096), (65536, 4096), (65536, 16384), (1 << 20, 16384)):
+        for chunk, batch in ((8192, 4096), (65536, 4096), (65536, 16384), (1 << 18, 16384), (1 << 20, 16384)):
             run(["rx", 1, chunk, batch, f_tr, f_iq], ns, "rx      window %7d batch %5d" % (chunk, batch), pin)
     if n <= 20000:
         run(["chain", 1, 65536, 4096, f_tr, f_iq], ns, "signal->demod->decode, 65536/4096")
     run(["capture", 1, 65536, f_iq], ns, "capture window   65536")
     for pin in (True, False):
-        for chunk, batch in ((65536, 4096), (65536, 16384), (1 << 20, 16384)):
-            run(["decode", chunk, batch, f_tg, f_llr], ns, "decode  window %7d batch %5d" % (chunk, batch), pin)
+        for chunk, batch in ((65536, 4096), (65536, 16384), (1 << 18, 16384), (1 << 20, 16384)):
+            run(["decode", chunk, batch, f_tg, f_llr], ns_dec, "decode  window %7d batch %5d" % (chunk, batch), pin)
     for f in (f_iq, f_tr, f_llr, f_tg):
         os.remove(f)
 

@@ -21,7 +21,7 @@ rm -rf /tmp/strace
 GR80211_PUMP_QUIET=1 timeout -k 10 200 rocprofv3 --kernel-trace --output-format csv -d /tmp/strace -- $R/fork-gr-ieee80211_amd/gr80211_pump rx 1 $2 $3 /tmp/sp/trig.txt /tmp/sp/iq0.bin > /tmp/strace.log 2>&1 || { tail -5 /tmp/strace.log; exit 1; }
 F=$(find /tmp/strace -name '*kernel_trace.csv' | head -1)
 python3 - "$F" <<'PY'
-import csv, re, sys, collections
+import csv, re, sys, collections, statistics
 def short(name):
     m = re.search(r"k_\w+", name)
     return m.group(0) if m else name[:24]
@@ -52,6 +52,19 @@ if len(dec) > 6:
         skipped = 0
         last = e[2]
         print(line)
+# pull kernels beside a decoder's forward pass and on their own: how long they take, and how much of the time one runs
+def busy(lo, hi):
+    return sum(max(0, min(p[1], hi) - max(p[0], lo)) for p in pull)
+t_dec = sum(d[1] - d[0] for d in dec)
+b_in = sum(busy(d[0], d[1]) for d in dec)
+span = ev[-1][1] - dec[0][0] if dec else 1
+b_all = busy(dec[0][0], ev[-1][1]) if dec else 0
+ins = [p for p in pull if any(d[0] <= p[0] <= d[1] for d in dec)]
+outs = [p for p in pull if dec and p[0] >= dec[0][0] and not any(d[0] <= p[0] <= d[1] for d in dec)]
+md = lambda v: statistics.median([(p[1] - p[0]) / 1e3 for p in v]) if v else 0.0
+import statistics
+print("beside a forward pass: %d pull kernels, median %.1f us, one running %.0f %% of the time; otherwise: %d, median %.1f us, %.0f %%" %
+      (len(ins), md(ins), 100.0 * b_in / max(1, t_dec), len(outs), md(outs), 100.0 * (b_all - b_in) / max(1, span - t_dec)))
 gaps = [(pull[i + 1][0] - pull[i][1]) / 1e3 for i in range(len(pull) - 1)]
 dur = [(p[1] - p[0]) / 1e3 for p in pull]
 import statistics

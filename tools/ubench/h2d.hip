@@ -12,13 +12,16 @@ __global__ __launch_bounds__(256) void k_pull(u4 *__restrict__ dst, const u4 *__
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) dst[i] = __builtin_nontemporal_load(src + i);
 }
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
-int main()
+int main(int argc, char **argv)
 {
-    const size_t total = (size_t)1 << 30;
+    // h2d [GiB of page-locked source, default 1] [1: write every byte of it first, default 0: one byte per page]
+    const size_t total = (size_t)(argc > 1 ? atoi(argv[1]) : 1) << 30;
+    const bool fill = argc > 2 && atoi(argv[2]) != 0;
     char *h, *d;
     CK(hipHostMalloc((void **)&h, total));
     CK(hipMalloc((void **)&d, total));
-    for (size_t i = 0; i < total; i += 4096) h[i] = (char)i;
+    if (fill) for (size_t i = 0; i < total; i++) h[i] = (char)(i * 7);
+    else for (size_t i = 0; i < total; i += 4096) h[i] = (char)i;
     hipStream_t s[4];
     for (auto &x : s) CK(hipStreamCreate(&x));
     CK(hipMemcpy(d, h, total, hipMemcpyHostToDevice));
