@@ -7,6 +7,11 @@
 #include <cstdlib>
 #include <cstring>
 
+#include <arpa/inet.h>
+#include <netdb.h>
+#include <sys/socket.h>
+#include <unistd.h>
+
 namespace gr80211 {
 namespace host {
 
@@ -448,6 +453,41 @@ int out_stream::pop(void *dst, int max_items, uint64_t written, std::vector<tag_
 }
 
 std::string gpu_session::error() const { return d_ctx ? gr80211_last_error(d_ctx) : "no GPU context"; }
+
+// ------------------------------------------------------------------------------------ udp_sink
+udp_sink::~udp_sink()
+{
+    if (d_fd >= 0) ::close(d_fd);
+}
+
+bool udp_sink::open(const std::string &host, int port)
+{
+    if (d_fd >= 0) ::close(d_fd);
+    d_fd = -1;
+    if (port < 1 || port > 65535) return false;
+    addrinfo hints;
+    memset(&hints, 0, sizeof(hints));
+    hints.ai_family = AF_INET;
+    hints.ai_socktype = SOCK_DGRAM;
+    addrinfo *res = nullptr;
+    if (getaddrinfo(host.c_str(), std::to_string(port).c_str(), &hints, &res) != 0 || !res) return false;
+    const int fd = ::socket(res->ai_family, res->ai_socktype, res->ai_protocol);
+    // connected: send() needs no address, and a port nobody listens on shows as an error of a later send
+    if (fd >= 0 && ::connect(fd, res->ai_addr, res->ai_addrlen) == 0) d_fd = fd;
+    else if (fd >= 0) ::close(fd);
+    freeaddrinfo(res);
+    return d_fd >= 0;
+}
+
+bool udp_sink::send(const pdu_t &m)
+{
+    if (d_fd < 0) return false;
+    const size_t n = std::min(m.blob.size(), MTU);
+    const ssize_t rc = ::send(d_fd, m.blob.data(), n, 0);
+    if (rc != (ssize_t)n) return false;
+    d_nSent++;
+    return true;
+}
 
 // ------------------------------------------------------------------------------------ decode
 decode::sptr decode::make(bool ifdebug, int batch_frames, int device)

@@ -253,6 +253,30 @@ private:
     std::deque<tag_t> d_tags;
 };
 
+// What the reference flowgraphs connect to decode's "out" port: a network.socket_pdu block of type UDP_CLIENT
+// (examples/cmu_v3/trxSta0.grc:301-313,1054: host 127.0.0.1, port 9527, MTU 65535), which sends the blob of every
+// PDU -- [format][len lo][len hi][payload][mcs] -- as one datagram.  Connect it with
+//     b->set_msg_handler([&](const std::string &, const pdu_t &m) { sink.send(m); });
+class udp_sink
+{
+public:
+    udp_sink() = default;
+    ~udp_sink();
+    udp_sink(const udp_sink &) = delete;
+    udp_sink &operator=(const udp_sink &) = delete;
+    // host: dotted IPv4 address or a name the resolver knows; false if the socket cannot be made
+    bool open(const std::string &host, int port);
+    bool is_open() const { return d_fd >= 0; }
+    // one datagram per message; blobs beyond the MTU are cut to it, as socket_pdu does.  false if the send failed
+    bool send(const pdu_t &m);
+    uint64_t datagrams_sent() const { return d_nSent; }
+    static constexpr size_t MTU = 65507;  // the longest UDP payload IPv4 carries (socket_pdu's 65535 less the headers)
+
+private:
+    int d_fd = -1;
+    uint64_t d_nSent = 0;
+};
+
 class decode : public block
 {
 public:

@@ -16,6 +16,11 @@ struct gr80211_block {
     void *user = nullptr;
     std::string err;
     std::vector<tag_t> out_tags;  // of the last call: the records handed out point into them
+    udp_sink udp;                 // open: every message also leaves as a datagram
+};
+
+struct gr80211_udp {
+    udp_sink sink;
 };
 
 namespace {
@@ -53,12 +58,55 @@ gr80211_block *gr80211_block_create(int kind, int batch_frames, int device)
     }
     gr80211_block *raw = h.release();
     raw->b->set_msg_handler([raw](const std::string &, const pdu_t &m) {
+        if (raw->udp.is_open()) raw->udp.send(m);
         if (raw->fn) raw->fn(raw->user, m.blob.data(), (int)m.blob.size());
     });
     return raw;
 }
 
 void gr80211_block_destroy(gr80211_block *b) { delete b; }
+
+void *gr80211_block_alloc_input(gr80211_block *b, uint64_t bytes) { return b ? b->b->alloc_input((size_t)bytes) : nullptr; }
+
+void gr80211_block_free_input(gr80211_block *b, void *p)
+{
+    if (b && p) b->b->free_input(p);
+}
+
+int gr80211_block_pin_input(gr80211_block *b, const void *p, uint64_t bytes)
+{
+    if (!b) return -1;
+    return b->b->pin_input(p, (size_t)bytes) ? 0 : -1;
+}
+
+int gr80211_block_send_udp(gr80211_block *b, const char *host, int port)
+{
+    if (!b) return -1;
+    if (!host) {
+        b->udp.open("", 0);  // closes
+        return 0;
+    }
+    return b->udp.open(host, port) ? 0 : -1;
+}
+
+gr80211_udp *gr80211_udp_open(const char *host, int port)
+{
+    if (!host) return nullptr;
+    std::unique_ptr<gr80211_udp> u(new gr80211_udp());
+    if (!u->sink.open(host, port)) return nullptr;
+    return u.release();
+}
+
+int gr80211_udp_send(gr80211_udp *u, const uint8_t *blob, int len)
+{
+    if (!u || !blob || len < 0) return -1;
+    pdu_t m;
+    m.blob.assign(blob, blob + len);
+    m.len = len;
+    return u->sink.send(m) ? 0 : -1;
+}
+
+void gr80211_udp_close(gr80211_udp *u) { delete u; }
 
 void gr80211_block_set_msg_handler(gr80211_block *b, gr80211_msg_fn fn, void *user)
 {

@@ -11,6 +11,10 @@
 //   gr80211_pump decode <chunk> <batch> <tags.txt> <llr.bin>
 //       tags.txt: one "offset format len total cr mcs ampdu trellis" line per packet; llr.bin: float32
 //
+//   --udp <host>:<port> before the mode: every message also leaves as one UDP datagram holding its blob, as the
+//       network.socket_pdu (UDP_CLIENT) block behind decode's "out" port sends it in the reference flowgraphs
+//       (examples/cmu_v3/trxSta0.grc:301-313,1054)
+//
 // Output: "PDU <hex of the message blob>" per message (not with GR80211_PUMP_QUIET=1 in the environment), then
 // "STAT ..." counters and the seconds spent between the first general_work call and the end of flush().
 // Exit code 0 on success.
@@ -73,8 +77,12 @@ struct stream_buf {
 static bool g_quiet = false;
 static double g_seconds = 0.0;
 
+static udp_sink g_udp;
+static uint64_t g_udp_failed = 0;
+
 static void on_msg(const std::string &, const pdu_t &m)
 {
+    if (g_udp.is_open() && !g_udp.send(m)) g_udp_failed++;
     if (g_quiet) return;
     std::string hex;
     static const char *d = "0123456789abcdef";
@@ -181,9 +189,29 @@ static bool step(block &b, std::vector<link *> in, std::vector<link *> out, int 
     return true;
 }
 
+static int run(int argc, char **argv);
+
 int main(int argc, char **argv)
 {
     if (const char *q = getenv("GR80211_PUMP_QUIET")) g_quiet = q[0] == '1';
+    if (argc >= 3 && !strcmp(argv[1], "--udp")) {
+        const std::string dest = argv[2];
+        const size_t colon = dest.rfind(':');
+        if (colon == std::string::npos || !g_udp.open(dest.substr(0, colon), atoi(dest.c_str() + colon + 1))) {
+            fprintf(stderr, "cannot open a UDP socket to %s (want host:port)\n", dest.c_str());
+            return 2;
+        }
+        argv[2] = argv[0];
+        argv += 2;
+        argc -= 2;
+    }
+    const int rc = run(argc, argv);
+    if (g_udp.is_open()) printf("UDP datagrams=%llu failed=%llu\n", (unsigned long long)g_udp.datagrams_sent(), (unsigned long long)g_udp_failed);
+    return rc;
+}
+
+static int run(int argc, char **argv)
+{
     if (argc >= 7 && !strcmp(argv[1], "rx")) {
         const int n_rx = atoi(argv[2]), chunk = atoi(argv[3]), batch = atoi(argv[4]);
         rx::sptr b = rx::make(n_rx, batch, 0);
@@ -346,7 +374,8 @@ int main(int argc, char **argv)
         printf("TIME items=%zu seconds=%.6f\n", n, g_seconds);
         return ok ? 0 : 1;
     }
-    fprintf(stderr, "usage: gr80211_pump rx <n_rx> <chunk> <batch> <triggers.txt> <iq0.bin> [iq1.bin]\n"
+    fprintf(stderr, "usage: gr80211_pump [--udp host:port] <mode> ...\n"
+                    "       gr80211_pump rx <n_rx> <chunk> <batch> <triggers.txt> <iq0.bin> [iq1.bin]\n"
                     "       gr80211_pump chain <n_rx> <chunk> <batch> <triggers.txt> <iq0.bin> [iq1.bin]\n"
                     "       gr80211_pump capture <n_rx> <chunk> <iq0.bin> [iq1.bin]\n"
                     "       gr80211_pump decode <chunk> <batch> <tags.txt> <llr.bin>\n");

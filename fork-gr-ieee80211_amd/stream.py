@@ -16,7 +16,9 @@ OPT_MU_POS, OPT_AMPDU_STRICT = 0, 1
 EXPORTS = ("gr80211_block_create", "gr80211_block_destroy", "gr80211_block_set_msg_handler",
            "gr80211_block_set_option", "gr80211_block_n_inputs", "gr80211_block_forecast", "gr80211_block_work",
            "gr80211_block_flush", "gr80211_block_last_error", "gr80211_block_n_outputs", "gr80211_block_work_out",
-           "gr80211_block_pending_output")
+           "gr80211_block_pending_output", "gr80211_block_alloc_input", "gr80211_block_free_input",
+           "gr80211_block_pin_input", "gr80211_block_send_udp")
+UDP_EXPORTS = ("gr80211_udp_open", "gr80211_udp_send", "gr80211_udp_close")
 
 
 class Tag(ctypes.Structure):
@@ -60,6 +62,17 @@ def load_host_library():
     L.gr80211_block_flush.argtypes = [vp]
     L.gr80211_block_last_error.restype = ctypes.c_char_p
     L.gr80211_block_last_error.argtypes = [vp]
+    L.gr80211_block_alloc_input.restype = vp
+    L.gr80211_block_alloc_input.argtypes = [vp, ctypes.c_uint64]
+    L.gr80211_block_free_input.restype = None
+    L.gr80211_block_free_input.argtypes = [vp, vp]
+    L.gr80211_block_pin_input.argtypes = [vp, vp, ctypes.c_uint64]
+    L.gr80211_block_send_udp.argtypes = [vp, ctypes.c_char_p, ci]
+    L.gr80211_udp_open.restype = vp
+    L.gr80211_udp_open.argtypes = [ctypes.c_char_p, ci]
+    L.gr80211_udp_send.argtypes = [vp, ctypes.c_char_p, ci]
+    L.gr80211_udp_close.restype = None
+    L.gr80211_udp_close.argtypes = [vp]
     _lib = L
     return L
 
@@ -97,6 +110,10 @@ class StreamBlock:
         if rc < 0:
             raise RuntimeError("%s: %s" % (what, self.lib.gr80211_block_last_error(self.h).decode()))
         return rc
+
+    def send_udp(self, host, port):
+        """Every message the block publishes also leaves as one UDP datagram to host:port (host None: stop)."""
+        self._check(self.lib.gr80211_block_send_udp(self.h, host.encode() if host else None, int(port)), "send_udp")
 
     def set_option(self, option, value):
         self._check(self.lib.gr80211_block_set_option(self.h, option, int(value)), "set_option")

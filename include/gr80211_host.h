@@ -106,6 +106,29 @@ int gr80211_block_work_out(gr80211_block *b, int noutput_items, const int *ninpu
                            int n_inputs, const gr80211_tag *tags, int n_tags, void *const *output_items, int n_outputs,
                            gr80211_tag *tags_out, int cap_tags_out, int *n_tags_out, int *consumed);
 long long gr80211_block_pending_output(const gr80211_block *b);
+/*
+ * Page-locked input buffers.  Windows that lie in memory from gr80211_block_alloc_input travel to the GPU
+ * asynchronously at the rate of the link, and a call then consumes the items whose copies have run, which may be
+ * fewer than it was offered (never none); windows in other memory are copied before the call returns.  A GNU Radio
+ * 3.10 wrapper hands the memory out through a custom buffer type of the block's input ports; the scheduler of the
+ * reference's GNU Radio allocates its own buffers, which gr80211_block_pin_input page-locks in place where the system
+ * allows it (0 on success; ordinary copies are used otherwise).  Buffers are freed with the block at the latest.
+ */
+void *gr80211_block_alloc_input(gr80211_block *b, uint64_t bytes);
+void gr80211_block_free_input(gr80211_block *b, void *p);
+int gr80211_block_pin_input(gr80211_block *b, const void *p, uint64_t bytes);
+/*
+ * The UDP hand-off of the reference flowgraphs: decode's "out" port feeds a network.socket_pdu block of type
+ * UDP_CLIENT (examples/cmu_v3/trxSta0.grc:301-313,1054; 127.0.0.1:9527), which sends every PDU's blob --
+ * [format][len lo][len hi][payload][mcs] -- as one datagram.  gr80211_block_send_udp makes the block do the same
+ * with every message it publishes, besides calling the handler (host == NULL: stop); 0 on success.
+ * gr80211_udp_* is the sender on its own, for a caller that publishes blobs itself.
+ */
+int gr80211_block_send_udp(gr80211_block *b, const char *host, int port);
+typedef struct gr80211_udp gr80211_udp;
+gr80211_udp *gr80211_udp_open(const char *host, int port);
+int gr80211_udp_send(gr80211_udp *u, const uint8_t *blob, int len); /* 0 when the datagram has left */
+void gr80211_udp_close(gr80211_udp *u);
 /* End of stream: decode what is buffered.  0 on success. */
 int gr80211_block_flush(gr80211_block *b);
 /* Text of the block's last error; with b == NULL, why the calling thread's last gr80211_block_create returned NULL. */

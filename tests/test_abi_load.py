@@ -3,6 +3,8 @@ import ctypes
 import os
 import re
 
+import numpy as np
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -67,10 +69,53 @@ def test_streaming_abi_symbols_exported(pkg):
     lib = stream.load_host_library()
     for n in names:
         assert hasattr(lib, n), n
+    for n in stream.UDP_EXPORTS:
+        assert n in declared_functions("gr80211_host.h") and hasattr(lib, n), n
     assert ctypes.sizeof(stream.Tag) == 40
     assert not lib.gr80211_block_create(99, 0, 0)
     assert b"unknown block kind" in lib.gr80211_block_last_error(None)
     assert lib.gr80211_block_n_inputs(None) == -1 and lib.gr80211_block_flush(None) == -1
+
+
+def test_udp_sender_one_datagram_per_blob(pkg):
+    """The UDP hand-off of the reference flowgraphs (socket_pdu UDP_CLIENT behind decode's "out" port,
+    examples/cmu_v3/trxSta0.grc:301-313,1054): every blob [format][len lo][len hi][payload][mcs] arrives as one
+    datagram with exactly its bytes, in order on the loopback; an empty blob and one of the largest size a datagram
+    carries pass too, a longer one is cut to that size.  No GPU involved."""
+    import socket
+    from importlib import import_module
+    stream = import_module("fork-gr-ieee80211_amd.stream")
+    lib = stream.load_host_library()
+    rx = socket.socket(socket.AF_INET, socket.SOCK_DGRAM)
+    rx.setsockopt(socket.SOL_SOCKET, socket.SO_RCVBUF, 1 << 22)
+    rx.bind(("127.0.0.1", 0))
+    rx.settimeout(5.0)
+    port = rx.getsockname()[1]
+    assert not lib.gr80211_udp_open(b"127.0.0.1", 0) and not lib.gr80211_udp_open(None, port)
+    assert lib.gr80211_udp_send(None, b"x", 1) == -1
+    u = lib.gr80211_udp_open(b"127.0.0.1", port)
+    assert u
+    rng = np.random.default_rng(5)
+    blobs = []
+    for fmt, n, mcs in ((0, 100, 3), (1, 1500, 7), (2, 4095, 8), (2, 1, 0)):
+        payload = rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+        blobs.append(bytes([fmt, n & 255, n >> 8]) + payload + bytes([mcs]))
+    blobs.append(b"")
+    blobs.append(bytes(65507))
+    try:
+        for b in blobs:
+            assert lib.gr80211_udp_send(u, b, len(b)) == 0
+            got, _ = rx.recvfrom(1 << 17)
+            assert got == b
+            if len(b) > 3:
+                assert len(got) == 3 + (got[1] | got[2] << 8) + 1 or got[0] == 0 and len(got) == 65507
+        long_one = bytes(range(256)) * 300
+        assert lib.gr80211_udp_send(u, long_one, len(long_one)) == 0
+        got, _ = rx.recvfrom(1 << 17)
+        assert got == long_one[:65507]
+    finally:
+        lib.gr80211_udp_close(u)
+        rx.close()
 
 
 def test_tx_frame_lengths_match_generator(pkg):

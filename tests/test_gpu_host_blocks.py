@@ -92,6 +92,62 @@ def test_rx_block_siso_stream(tmp_path, oracle, chunk, batch):
     assert mpdus == [f["mpdu"] for f in frames]
 
 
+class UdpListener:
+    """Collects the datagrams that arrive on a loopback port of its own."""
+
+    def __init__(self):
+        import socket
+        import threading
+        self.sock = socket.socket(socket.AF_INET, socket.SOCK_DGRAM)
+        self.sock.setsockopt(socket.SOL_SOCKET, socket.SO_RCVBUF, 1 << 22)
+        self.sock.bind(("127.0.0.1", 0))
+        self.sock.settimeout(0.2)
+        self.port = self.sock.getsockname()[1]
+        self.got = []
+        self._stop = False
+        self._th = threading.Thread(target=self._run, daemon=True)
+        self._th.start()
+
+    def _run(self):
+        import socket
+        quiet = 0
+        while quiet < 5 or not self._stop:
+            try:
+                self.got.append(self.sock.recvfrom(1 << 17)[0])
+                quiet = 0
+            except socket.timeout:
+                quiet += 1 if self._stop else 0
+
+    def finish(self):
+        self._stop = True
+        self._th.join(10)
+        self.sock.close()
+        return self.got
+
+
+def test_pdus_leave_as_udp_datagrams(tmp_path, pkg, oracle):
+    """The hand-off of the reference flowgraphs (socket_pdu UDP_CLIENT behind decode's "out" port,
+    examples/cmu_v3/trxSta0.grc:301-313,1054): with --udp the command-line scheduler, and with send_udp a block of
+    the streaming C-ABI, send every published blob as one datagram; what arrives equals the messages, in order."""
+    iq0, triggers, frames = siso_stream(0.002, 6)
+    want, n_frames = model_chain(oracle, iq0, None, triggers)
+    tf, files = write_stream(tmp_path, iq0, None, triggers)
+    ear = UdpListener()
+    got, stat = run_pump(["--udp", "127.0.0.1:%d" % ear.port, "rx", 1, 4096, 3, tf] + files)
+    heard = ear.finish()
+    assert got == want and heard == want
+    # the same through the C-ABI block
+    from importlib import import_module
+    stream = import_module("fork-gr-ieee80211_amd.stream")
+    sync, tags = sync_stream(len(iq0), triggers)
+    ear = UdpListener()
+    with stream.StreamBlock(stream.RX, 3) as b:
+        b.send_udp("127.0.0.1", ear.port)
+        msgs = b.run([sync, iq0], tags, 4096)
+    heard = ear.finish()
+    assert msgs == want and heard == want
+
+
 def test_rx_block_false_lsig_swallows_stream(tmp_path, oracle):
     """With this noise seed the tagged sync byte on silence passes the L-SIG check by chance and announces a
     frame longer than the rest of the stream: like `signal`, the block must then ignore every later trigger and
