@@ -769,3 +769,45 @@ def test_resume_after_signal_batch_equals_rx_batch(pkg, oracle):
     finally:
         ctx.close()
         ref.close()
+
+
+def test_copies_by_kernel_over_the_link(pkg, rxctx):
+    """gr80211_pull_h2d / gr80211_push_d2h: copies done by a kernel between page-locked host memory and the device, at
+    every alignment of source and destination a stream of items can have (16, 8, 4 bytes and none), sizes from one
+    byte to a few megabytes; gr80211_pull_done turns 1 in the order of the numbers handed out; memory that is not
+    page-locked is refused without leaving an error behind for the next call."""
+    import ctypes as C
+    lib, c = rxctx.lib, rxctx.h
+    n = (3 << 20) + 77
+    h_src = lib.gr80211_host_alloc(c, n + 64)
+    h_dst = lib.gr80211_host_alloc(c, n + 64)
+    d = lib.gr80211_dev_alloc(c, n + 64)
+    assert h_src and h_dst and d
+    try:
+        src = np.ctypeslib.as_array(C.cast(h_src, C.POINTER(C.c_uint8)), (n + 64,))
+        dst = np.ctypeslib.as_array(C.cast(h_dst, C.POINTER(C.c_uint8)), (n + 64,))
+        rng = np.random.default_rng(11)
+        src[:] = rng.integers(0, 256, n + 64, dtype=np.uint8)
+        last = 0
+        for so, do, size in ((0, 0, n), (8, 16, 1 << 20), (8, 8, 65536 + 8), (4, 12, 4097), (1, 3, 1000), (0, 0, 1), (16, 0, 255),
+                             (3, 16, (1 << 20) + 5)):
+            dst[:] = 0
+            num = lib.gr80211_pull_h2d(c, d + do, h_src + so, size, None)
+            assert num == last + 1, num
+            last = num
+            assert lib.gr80211_pull_done(c, num, 1) == 1 and lib.gr80211_pull_done(c, num, 0) == 1
+            assert lib.gr80211_push_d2h(c, h_dst + so, d + do, size, None) == 0
+            rxctx.sync()
+            assert np.array_equal(dst[so:so + size], src[so:so + size]), (so, do, size)
+            assert not dst[:so].any() and not dst[so + size:].any()
+        assert lib.gr80211_pull_done(c, last + 1, 0) < 0          # a number never handed out
+        plain = np.zeros(4096, np.uint8)
+        assert lib.gr80211_pull_h2d(c, d, plain.ctypes.data, 4096, None) < 0
+        assert lib.gr80211_push_d2h(c, plain.ctypes.data, d, 4096, None) < 0
+        # and the context is as good as before
+        num = lib.gr80211_pull_h2d(c, d, h_src, 4096, None)
+        assert num == last + 1 and lib.gr80211_pull_done(c, num, 1) == 1
+    finally:
+        lib.gr80211_dev_free(c, d)
+        lib.gr80211_host_free(c, h_src)
+        lib.gr80211_host_free(c, h_dst)
