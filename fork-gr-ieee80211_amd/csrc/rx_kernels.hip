@@ -1437,17 +1437,17 @@ __device__ __forceinline__ void fetch_tile(const float *__restrict__ llr, unsign
 // Forward pass of one group.  TWO_TILES: the wave has room for two tiles in LDS (a batch of at most one group per
 // SIMD) and fetches the next chunk's soft bits while it works on this one; a wave that shares its SIMD leaves the
 // fetch latency to its partner instead.
+// Chunks [ch0, ch1) of a group's forward pass: A holds the path metrics before chunk ch0 on entry and after chunk
+// ch1 - 1 on return (a chunk is an even number of steps, so the metrics end where they started).
 template <int CR, bool TWO_TILES>
-__device__ __forceinline__ void viterbi_group(const float *__restrict__ llr, unsigned long long mybase, int myn,
-                                              int nchunks, uint32_t *__restrict__ dec, float *tile, int lane)
+__device__ __forceinline__ void viterbi_chunks(float (&A)[64], const float *__restrict__ llr, unsigned long long mybase, int myn,
+                                               int ch0, int ch1, uint32_t *__restrict__ dec, float *tile, int lane)
 {
     constexpr int P = Rate<CR>::P, COLS = Rate<CR>::COLS, NPER = Rate<CR>::NPER;
     constexpr int CH = COLS * NPER;    // LLR columns per tile
     constexpr int STEPS = P * NPER;    // trellis steps per tile
     static_assert(STEPS / 2 < 63, "the wait below counts one survivor store per step pair");
-    float A[64], B[64];
-#pragma unroll
-    for (int i = 0; i < 64; i++) A[i] = i == 0 ? 0.0f : NEG_INIT;
+    float B[64];
 #ifndef GR80211_PRIO_SHIFT
 #define GR80211_PRIO_SHIFT 13
 #endif
@@ -1462,18 +1462,18 @@ __device__ __forceinline__ void viterbi_group(const float *__restrict__ llr, uns
     for (int d = 32; d > 0; d >>= 1) least = min(least, __shfl_xor(least, d));
     least = __builtin_amdgcn_readfirstlane(least);
     lds_float *lt = (lds_float *)tile;  // the wave's tile(s), as the LDS addresses the DMA loads take
-    if (TWO_TILES) fetch_tile(llr, mybase, myn, least, 0, lane, lt);
-    for (int ch = 0; ch < nchunks; ch++) {
+    if (TWO_TILES && ch0 < ch1) fetch_tile(llr, mybase, myn, least, ch0 * CH, lane, lt + (ch0 & 1) * (64 * TILE_STRIDE));
+    for (int ch = ch0; ch < ch1; ch++) {
         float *cur = tile;
         if (TWO_TILES) {
             cur = tile + (ch & 1) * (64 * TILE_STRIDE);
             // this chunk's soft bits were requested a chunk ago; the only younger memory operations are the
             // survivor stores of the chunk in between (none before the first chunk), which may stay in flight
-            if (ch == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (ch == ch0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(STEPS / 2) : "memory");
             // the other tile's last readers were the steps of the previous chunk: their values have arrived
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (ch + 1 < nchunks) fetch_tile(llr, mybase, myn, least, (ch + 1) * CH, lane, lt + ((ch + 1) & 1) * (64 * TILE_STRIDE));
+            if (ch + 1 < ch1) fetch_tile(llr, mybase, myn, least, (ch + 1) * CH, lane, lt + ((ch + 1) & 1) * (64 * TILE_STRIDE));
         } else {
             if ((((unsigned)(__builtin_amdgcn_s_memrealtime() >> GR80211_PRIO_SHIFT)) ^ slot_parity) & 1u)
                 __builtin_amdgcn_s_setprio(2);
@@ -1492,6 +1492,17 @@ __device__ __forceinline__ void viterbi_group(const float *__restrict__ llr, uns
         for (int pp = 0; pp < NPER; pp += 2)
             two_periods<CR>(A, B, row + pp * COLS, dp + (size_t)pp * P * 128, std::make_integer_sequence<int, P>{});
     }
+}
+
+// Forward pass of one group from its first chunk to its last.
+template <int CR, bool TWO_TILES>
+__device__ __forceinline__ void viterbi_group(const float *__restrict__ llr, unsigned long long mybase, int myn,
+                                              int nchunks, uint32_t *__restrict__ dec, float *tile, int lane)
+{
+    float A[64];
+#pragma unroll
+    for (int i = 0; i < 64; i++) A[i] = i == 0 ? 0.0f : NEG_INIT;
+    viterbi_chunks<CR, TWO_TILES>(A, llr, mybase, myn, 0, nchunks, dec, tile, lane);
 }
 
 __global__ __launch_bounds__(64) void k_viterbi(const float *__restrict__ llr, const gr80211_frame_info *__restrict__ info,
