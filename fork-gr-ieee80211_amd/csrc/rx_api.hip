@@ -495,18 +495,23 @@ __global__ __launch_bounds__(256) void k_pull(V *__restrict__ dst, const V *__re
                                               unsigned char *__restrict__ dst_tail, const unsigned char *__restrict__ src_tail,
                                               int n_tail, unsigned *__restrict__ finished, uint32_t *__restrict__ flag, uint32_t number)
 {
+    // a few short waves that wait on the link: beside decoder waves they should issue whenever they can
+    __builtin_amdgcn_s_setprio(3);
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_wide; i += stride)
         dst[i] = __builtin_nontemporal_load(src + i);
     if (blockIdx.x == 0 && (int)threadIdx.x < n_tail) dst_tail[threadIdx.x] = src_tail[threadIdx.x];
-    // every load of this workgroup has returned once its threads are here (each store above needed its load's data)
     if (!flag) return;  // a copy nobody waits for by number
+    // The number tells the host that the source has been read, nothing about the destination (work that follows on
+    // the stream sees that as usual): every load of this workgroup has returned once its threads are here (each
+    // store above needed its load's data), so plain relaxed operations do -- a release here would write back the
+    // whole L2 of an XCD for every workgroup, with a decoder's survivor words in it.
     __syncthreads();
     if (threadIdx.x == 0) {
-        const unsigned before = __hip_atomic_fetch_add(finished, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned before = __hip_atomic_fetch_add(finished, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (before == gridDim.x - 1) {
             __hip_atomic_store(finished, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // for the next copy of this stream
-            __hip_atomic_store(flag, number, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(flag, number, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
 }

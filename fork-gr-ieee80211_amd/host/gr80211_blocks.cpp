@@ -955,25 +955,30 @@ int rx::take_input(gr_vector_int &ninput_items, gr_vector_const_void_star &input
     const int lo = (int)std::min<uint64_t>(log.enqueued() - r0, (uint64_t)n);
     if (lo < n) {
         round &f = *d_fill;
-        std::vector<tag_t> tags;
-        const size_t trig_before = f.trig.size();
-        stopwatch *sw_scan = new stopwatch(d_tScan, d_profile ? "scan" : nullptr);
-        static const char *const keys[3] = {"rad", "snr", "rssi"};
-        for (int i = next_set(sync, lo, n); i < n; i = next_set(sync, i + 1, n)) {
-            const uint64_t at = r0 + (uint64_t)i;
-            double v[3] = {0.0, 0.0, 0.0};
-            if (!tag_values_at(0, at, keys, v, 3)) continue;  // "input sync with no tag" (lib/signal_impl.cc:96-100): not a trigger
-            trigger t;
-            t.pos = at;
-            t.rad = (float)v[0];
-            t.snr = (float)v[1];
-            t.rssi = (float)v[2];
-            f.trig.push_back(t);
-            d_nTrig++;
-        }
-        f.n_new += f.trig.size() - trig_before;
-        delete sw_scan;
-        stopwatch sw_up(d_tUpload, d_profile ? "upload" : nullptr);
+        // the new sync bytes with a tag become pending triggers
+        auto scan = [&]() {
+            stopwatch sw_scan(d_tScan, d_profile ? "scan" : nullptr);
+            const size_t trig_before = f.trig.size();
+            static const char *const keys[3] = {"rad", "snr", "rssi"};
+            for (int i = next_set(sync, lo, n); i < n; i = next_set(sync, i + 1, n)) {
+                const uint64_t at = r0 + (uint64_t)i;
+                double v[3] = {0.0, 0.0, 0.0};
+                if (!tag_values_at(0, at, keys, v, 3)) continue;  // "input sync with no tag" (lib/signal_impl.cc:96-100): not a trigger
+                trigger t;
+                t.pos = at;
+                t.rad = (float)v[0];
+                t.snr = (float)v[1];
+                t.rssi = (float)v[2];
+                f.trig.push_back(t);
+                d_nTrig++;
+            }
+            f.n_new += f.trig.size() - trig_before;
+        };
+        // A round that holds samples takes all of the new ones, so they are sent on their way first and the sync bytes
+        // are read while they travel; an empty round starts at its first sync byte, which has to be found first.
+        const bool scan_first = f.n == 0;
+        if (scan_first) scan();
+        std::unique_ptr<stopwatch> sw_up(new stopwatch(d_tUpload, d_profile ? "upload" : nullptr));
         // samples are only held from the first pending sync byte on
         int from = lo;
         if (f.n == 0) {
@@ -1005,6 +1010,8 @@ int rx::take_input(gr_vector_int &ninput_items, gr_vector_const_void_star &input
         } else {
             log.add(nullptr, 0, r0 + (uint64_t)n);
         }
+        sw_up.reset();
+        if (!scan_first) scan();
         log.set_enqueued(r0 + (uint64_t)n);
         // a round is cut when enough sync bytes are pending (the frame a round carried over counts once its samples
         // have come in), or when it holds as many samples as it may
