@@ -30,6 +30,15 @@ struct stopwatch {  // adds the time it lives to a counter; with a name, says so
     }
 };
 
+// True, and the time noted, if 100 us have passed since the time noted last.
+bool poll_due(std::chrono::steady_clock::time_point &last)
+{
+    const auto t = std::chrono::steady_clock::now();
+    if (t - last < std::chrono::microseconds(100)) return false;
+    last = t;
+    return true;
+}
+
 const int LSIG_SPAN = 224;       // samples from the trigger to the end of L-SIG (lib/signal_impl.cc:110,154)
 const int F_VHT_CHAN = 20;       // format byte of the sounding channel message (lib/cloud80211phy.h:40)
 const int LSIG_FAIL_SKIP = 80;   // samples dropped after a failed L-SIG check (lib/signal_impl.cc:156-160)
@@ -606,8 +615,8 @@ int decode::general_work(int, gr_vector_int &ninput_items, gr_vector_const_void_
     upload_log &log = d_up.log();
     if (log.enqueued() < r0) log.set_enqueued(r0);
     d_nCalls++;
-    // asking the runtime about the rounds in flight costs a few us: not every call
-    if ((d_nCalls & 3) == 0 && !d_flight.empty() && !advance(false, false)) return 0;
+    // asking the runtime about the rounds in flight costs a few us: at most every 100 us
+    if (!d_flight.empty() && poll_due(d_lastPoll) && !advance(false, false)) return 0;
     // items [used, n) of the window are new; the ones before were taken by an earlier call and wait for their copies
     int used = (int)std::min<uint64_t>(log.enqueued() - r0, (uint64_t)n);
     int span = used;  // window items from here on have not been sent yet
@@ -947,7 +956,7 @@ int rx::take_input(gr_vector_int &ninput_items, gr_vector_const_void_star &input
     upload_log &log = d_up.log();
     if (log.enqueued() < r0) log.set_enqueued(r0);
     d_nCalls++;
-    if ((d_nCalls & 3) == 0 && !d_flight.empty()) {  // asking the runtime about the rounds in flight costs a few us: not every call
+    if (!d_flight.empty() && poll_due(d_lastPoll)) {  // asking the runtime about the rounds in flight costs a few us: at most every 100 us
         stopwatch sw(d_tAdvance, d_profile ? "advance" : nullptr);
         if (!advance(false, false)) return -1;
     }

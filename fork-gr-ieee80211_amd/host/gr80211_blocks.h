@@ -336,6 +336,7 @@ private:
     long t_format = 0, t_len = 0, t_nTotal = 0, t_cr = 0, t_mcs = 0, t_ampdu = 0, v_trellis = 0;
     long t_nProcd = 0;
     uint64_t d_nSeen = 0, d_nPdu = 0, d_nRounds = 0, d_nCalls = 0;
+    std::chrono::steady_clock::time_point d_lastPoll{};  // when the rounds in flight were last asked after
 };
 
 class rx : public block
@@ -419,6 +420,7 @@ protected:
     // where the host's time goes (seconds), printed when the block goes if GR80211_BLOCK_PROFILE is set
     double d_tScan = 0, d_tUpload = 0, d_tSettle = 0, d_tAdvance = 0, d_tCut = 0, d_tPublish = 0;
     uint64_t d_nCalls = 0;
+    std::chrono::steady_clock::time_point d_lastPoll{};  // when the rounds in flight were last asked after
     bool d_profile = false;
     std::chrono::steady_clock::time_point d_t0 = std::chrono::steady_clock::now();
     double now() const { return std::chrono::duration<double>(std::chrono::steady_clock::now() - d_t0).count(); }
