@@ -647,10 +647,22 @@ int gr80211_rx_batch(gr80211_ctx *c, const void *d_iq0, const void *d_iq1, uint6
     HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t s = pick(c, stream);
     const gr80211_frame_desc *dd = nullptr;
+    SchedTotals room = {};
+    const bool no_wait = (flags & GR80211_FLAG_NO_WAIT) != 0;
+    if (no_wait) {
+        // what the buffers hold is what the batch may use; groups are cut per code rate, so four may stay part full
+        if (c->llr.cap < 65 * sizeof(float) || c->dec.cap < 129 * sizeof(uint32_t) || c->bitsw.cap < 65 * sizeof(uint32_t))
+            return fail(c, GR80211_ERR_ARG, "gr80211_rx_batch: GR80211_FLAG_NO_WAIT before a batch without it has sized the work buffers");
+        room.n_groups = n / 64 + 4;
+        room.n_valid = n;
+        room.llr_floats = c->llr.cap / sizeof(float) - 64;
+        room.dec_words = c->dec.cap / sizeof(uint32_t) - 128;
+        room.bits_words = c->bitsw.cap / sizeof(uint32_t) - 64;
+    }
     int rc = front_end(c, s, d_iq0, d_iq1, arena_len, desc, n, flags, &dd);
     if (rc) return rc;
     rc = run_decode_stages(c, s, n, true, d_iq0, d_iq1, arena_len, dd, nullptr, d_out, out_stride, d_out_len, d_n_pdu, nullptr, 0,
-                           true, nullptr, nullptr);
+                           true, nullptr, nullptr, no_wait ? &room : nullptr);
     if (rc) return rc;
     if (d_info)
         HIP_TRY(c, hipMemcpyAsync(d_info, c->info.p, (size_t)n * sizeof(gr80211_frame_info), hipMemcpyDeviceToDevice, s));

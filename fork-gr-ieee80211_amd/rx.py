@@ -17,6 +17,7 @@ ST_NAMES = {0: "ok", 1: "drop_lsig", 2: "drop_len_check", 3: "drop_unsupported",
 ST_NAMES_INV = {v: k for k, v in ST_NAMES.items()}
 F_VHT_CHAN = 20  # format byte of a sounding channel message (C8P_F_VHT_CHAN, lib/cloud80211phy.h)
 FLAG_DESC_ON_DEVICE = 1
+FLAG_NO_WAIT = 2
 
 
 class FrameDesc(C.Structure):
@@ -272,9 +273,13 @@ class RxContext:
         self._check(rc, "gr80211_rx_batch")
         return dict(out=out, out_len=out_len, n_pdu=n_pdu, info=info, _keep=keep)
 
-    def rx_batch_into(self, iq0, iq1, desc, n_frames, out, out_len, n_pdu, info=None):
-        """Same as rx_batch with caller-owned output tensors (no allocation in the timed region)."""
+    def rx_batch_into(self, iq0, iq1, desc, n_frames, out, out_len, n_pdu, info=None, no_wait=False):
+        """Same as rx_batch with caller-owned output tensors (no allocation in the timed region).  no_wait: the call
+        queues the whole batch without waiting for the scheduler (GR80211_FLAG_NO_WAIT); last_batch_refused() tells,
+        once the stream has passed the batch, whether the work buffers were too small for it."""
         dp, flags, keep = self._desc_arg(desc)
+        if no_wait:
+            flags |= FLAG_NO_WAIT
         rc = self.lib.gr80211_rx_batch(
             self.h, C.c_void_p(iq0.data_ptr()), C.c_void_p(iq1.data_ptr()) if iq1 is not None else None,
             iq0.numel(), dp, n_frames, flags, C.c_void_p(out.data_ptr()), out.shape[1],
@@ -282,6 +287,11 @@ class RxContext:
             C.c_void_p(info.data_ptr()) if info is not None else None, self._stream())
         self._check(rc, "gr80211_rx_batch")
         return keep
+
+    def last_batch_refused(self):
+        """True if the last batch whose sizes the host supplied (rx_resume, decode_batch with host descriptors,
+        rx_batch_into(no_wait=True)) found too little room on the device and was not run.  Call after sync()."""
+        return self.lib.gr80211_last_batch_refused(self.h) != 0
 
     def rx_submit(self, iq0, iq1, desc, n_frames):
         """First half of rx_batch_into: preamble and scheduling are launched, nothing is waited for.  Returns what has

@@ -115,6 +115,14 @@ typedef struct {
 } gr80211_sig_desc; /* 48 bytes */
 
 #define GR80211_FLAG_DESC_ON_DEVICE 1u /* the descriptor array argument is a device pointer */
+/*
+ * gr80211_rx_batch only: do not wait for the scheduler's totals in the middle of the batch.  The work buffers stay as
+ * large as the batches before have made them (a first batch without the flag sizes them), the kernels are launched
+ * for the most groups the frame count allows and take the real count from the device, and the call returns with
+ * everything queued.  A batch that needs more room than there is is not run: after the stream has passed it,
+ * gr80211_last_batch_refused says so, no PDU has been written, and the caller repeats the batch without the flag.
+ */
+#define GR80211_FLAG_NO_WAIT 2u
 
 /*
  * One two-user VHT MU-MIMO frame to transmit: the arguments of the reference's Python generator
@@ -170,6 +178,8 @@ int gr80211_sync(gr80211_ctx *ctx, void *stream);
  *        (lib/decode_impl.cc:359-361,414-419,512-516), only MPDUs whose FCS passes.
  * d_out_len[i] = bytes written for frame i, d_n_pdu[i] = number of PDUs.
  * d_info (nullable) receives the tag record of each frame.
+ * The call waits once, after the preamble stage, for the scheduler's totals (they size the work buffers) unless
+ * flags carries GR80211_FLAG_NO_WAIT; what follows that point is queued and the call returns.
  */
 int gr80211_rx_batch(gr80211_ctx *ctx, const void *d_iq0, const void *d_iq1, uint64_t arena_len,
                      const gr80211_frame_desc *desc, int n_frames, unsigned flags,

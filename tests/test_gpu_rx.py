@@ -771,6 +771,68 @@ def test_resume_after_signal_batch_equals_rx_batch(pkg, oracle):
         ref.close()
 
 
+def test_rx_batch_without_the_wait(pkg):
+    """gr80211_rx_batch with GR80211_FLAG_NO_WAIT: the whole batch is queued without the host reading the scheduler's
+    totals; PDUs and records equal those of the call that waits, for a batch of mixed formats with sync bytes on
+    noise among them and for part of it (fewer groups than the grid was launched for).  Before any batch has sized
+    the work buffers the flag is refused; a batch that needs more room than the batches before left is not run (flag
+    set, nothing written) and runs when repeated without the flag, after which the larger batch passes with it."""
+    import torch
+    tx = pkg.txgen
+    rng = np.random.default_rng(45)
+    frames = []
+    for k in range(200):
+        fmt = int(rng.integers(0, 3))
+        mcs = int(rng.integers(0, 8 if fmt < 2 else 9))
+        frames.append(make_noisy(tx, rng, fmt, mcs, 1, int(rng.integers(30, 1400)), 33.0)[0])
+        if k % 11 == 0:
+            noise = (0.1 * (rng.standard_normal(900) + 1j * rng.standard_normal(900))).astype(np.complex64)
+            frames.append(([noise], 300))
+    iq0, _, sync, navail = build_arena(frames)
+    n = len(frames)
+    d0 = torch.from_numpy(iq0).cuda()
+    desc = pkg.RxContext.make_desc(sync, navail)
+    ctx, ref = pkg.RxContext(0), pkg.RxContext(0)
+
+    def run(c, m, no_wait):
+        out = torch.zeros((m, 4104), dtype=torch.uint8, device="cuda")
+        out_len = torch.full((m,), -1, dtype=torch.int32, device="cuda")
+        n_pdu = torch.full((m,), -1, dtype=torch.int32, device="cuda")
+        info = torch.zeros(m * pkg.rx.FRAME_INFO_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
+        c.rx_batch_into(d0, None, desc[:m], m, out, out_len, n_pdu, info, no_wait=no_wait)
+        c.sync()
+        return out.cpu().numpy(), out_len.cpu().numpy(), n_pdu.cpu().numpy(), info.cpu().numpy().view(pkg.rx.FRAME_INFO_DTYPE)
+
+    def same(a, b):
+        assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+        assert all(bytes(a[0][i, : a[1][i]]) == bytes(b[0][i, : a[1][i]]) for i in range(len(a[1])))
+        for k in TAGS + ("nCBPS", "nDBPS", "llr_off", "status"):
+            assert np.array_equal(a[3][k], b[3][k]), k
+
+    try:
+        with pytest.raises(RuntimeError, match="before a batch without it"):
+            run(ctx, 8, True)
+        small = 70
+        want_small, want_all = run(ref, small, False), run(ref, n, False)
+        assert int(want_all[2].sum()) >= 195
+        run(ctx, small, False)                         # sizes the buffers for 70 frames
+        got = run(ctx, small, True)
+        assert not ctx.last_batch_refused()
+        same(got, want_small)
+        same(run(ctx, 40, True), run(ref, 40, False))  # a part of it: fewer groups than were launched for
+        got = run(ctx, n, True)                        # three times the frames: no room
+        assert ctx.last_batch_refused()
+        assert not got[1].any() and not got[2].any()
+        same(run(ctx, n, False), want_all)             # the call that waits makes room
+        assert not ctx.last_batch_refused()
+        got = run(ctx, n, True)
+        assert not ctx.last_batch_refused()
+        same(got, want_all)
+    finally:
+        ctx.close()
+        ref.close()
+
+
 def test_copies_by_kernel_over_the_link(pkg, rxctx):
     """gr80211_pull_h2d / gr80211_push_d2h: copies done by a kernel between page-locked host memory and the device, at
     every alignment of source and destination a stream of items can have (16, 8, 4 bytes and none), sizes from one
