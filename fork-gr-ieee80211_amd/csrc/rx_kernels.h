@@ -67,6 +67,9 @@ void launch_traceback(const uint32_t *dec, const gr80211_frame_info *info, const
 // same survivor words as launch_viterbi, to be followed by launch_traceback.
 void launch_viterbi_split(const float *llr, const gr80211_frame_info *info, const int32_t *slot_frame,
                           const GroupInfo *groups, int n_groups, uint32_t *dec, const SchedTotals *totals, hipStream_t s);
+// The same with two waves per group (states 0-31 / 32-63).
+void launch_viterbi_split2(const float *llr, const gr80211_frame_info *info, const int32_t *slot_frame,
+                          const GroupInfo *groups, int n_groups, uint32_t *dec, const SchedTotals *totals, hipStream_t s);
 void launch_decode(const float *llr, const gr80211_frame_info *info, const int32_t *slot_frame,
                    const GroupInfo *groups, int n_groups, uint32_t *dec, uint32_t *bitsw, uint8_t *out, int out_stride,
                    int32_t *out_len, int32_t *n_pdu, uint8_t *bits_out, int bits_stride, int strict,
@@ -81,6 +84,10 @@ __device__ __forceinline__ int groups_to_run(int n_groups, const SchedTotals *to
 #ifdef GR80211_TIMELINE
 int read_timeline(unsigned long long *dst, int n_groups);
 #endif
+// Two waves per group, forward pass and walk back in one kernel (k_decode_split2).
+void launch_decode_split2(const float *llr, const gr80211_frame_info *info, const int32_t *slot_frame, const GroupInfo *groups,
+                          int n_groups, uint32_t *dec, uint32_t *bitsw, uint8_t *out, int out_stride, int32_t *out_len,
+                          int32_t *n_pdu, uint8_t *bits_out, int bits_stride, int strict, const SchedTotals *totals, hipStream_t s);
 void launch_ndp_emit(const void *iq0, uint64_t arena_len, const gr80211_frame_desc *desc, int n,
                      const gr80211_frame_info *info, uint8_t *out, int out_stride, int32_t *out_len, int32_t *n_pdu,
                      hipStream_t s);

@@ -20,6 +20,7 @@
 #include <utility>
 
 #include "acs_common.h"
+#include "split_forward.h"
 #include "rx_kernels.h"
 
 namespace gr80211 {
@@ -1854,6 +1855,49 @@ __global__ __launch_bounds__(64 * WAVES) void k_decode(const float *__restrict__
 }
 
 // =========================================================================================
+// k_decode_split2: forward pass by two waves per group (split_forward.h), then the walk back by the wave that
+// stored the group's survivor words (wave 0 stores every record, so it reads back only what it stored itself) while
+// the other wave's SIMD goes to the next workgroup.  For batches of more groups than the four-wave form is good for
+// and at most one per SIMD: a lone one-trellis wave leaves half of its SIMD's issue slots unused.
+// =========================================================================================
+__global__ __launch_bounds__(128) void k_decode_split2(const float *__restrict__ llr, const gr80211_frame_info *__restrict__ info,
+                                                       const int32_t *__restrict__ slot_frame,
+                                                       const GroupInfo *__restrict__ groups, int n_groups,
+                                                       uint32_t *__restrict__ dec, uint32_t *__restrict__ bitsw,
+                                                       uint8_t *__restrict__ out, int out_stride, int32_t *__restrict__ out_len,
+                                                       int32_t *__restrict__ n_pdu, uint8_t *__restrict__ bits_out, int bits_stride,
+                                                       int strict, const SchedTotals *__restrict__ totals)
+{
+    n_groups = groups_to_run(n_groups, totals);
+    if ((int)blockIdx.x >= n_groups) return;  // whole workgroup
+    const int g = n_groups - 1 - (int)blockIdx.x;  // longest trellises first, as k_decode
+    const int lane = threadIdx.x & 63;
+    const int wi = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    __shared__ float tile[64 * TILE_STRIDE];
+    __shared__ float xch[2 * XCH2_BUF];
+    const GroupInfo gi = groups[g];
+    const int fr = slot_frame[g * 64 + lane];
+    const int myn = fr >= 0 ? info[fr].total : 0;
+    const unsigned long long mybase = myn > 0 ? (unsigned long long)info[fr].llr_off : 0ull;
+    uint32_t *d = dec + gi.dec_off;
+    switch (gi.cr) {
+    case CR_12: split2_dispatch<CR_12>(wi, llr, mybase, myn, gi.nchunks, d, tile, xch, lane); break;
+    case CR_23: split2_dispatch<CR_23>(wi, llr, mybase, myn, gi.nchunks, d, tile, xch, lane); break;
+    case CR_34: split2_dispatch<CR_34>(wi, llr, mybase, myn, gi.nchunks, d, tile, xch, lane); break;
+    default: split2_dispatch<CR_56>(wi, llr, mybase, myn, gi.nchunks, d, tile, xch, lane); break;
+    }
+    // the other wave's last look at the soft-bit tile came before the last barrier of the forward pass
+    if (wi != 0) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_setprio(3);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    uint32_t *s_crc = reinterpret_cast<uint32_t *>(tile);
+    for (int i = lane; i < 256; i += 64) s_crc[i] = c_tab.crc[i];
+    __builtin_amdgcn_wave_barrier();
+    traceback_group(dec, info, gi, fr, lane, s_crc, bitsw, out, out_stride, out_len, n_pdu, bits_out, bits_stride, strict);
+}
+
+// =========================================================================================
 // k_ndp_emit: the channel message of a sounding NDP (lib/decode_impl.cc:100-121): type byte 20, length 1024,
 // then the 64 + 64 time samples of the two VHT-LTF FFT windows as `signal` forwards them, i.e. CFO-derotated
 // (lib/demod_impl.cc:397-398: copies of sig1[8..72) and sig1[88..152) of the samples after VHT-STF).
@@ -2046,6 +2090,13 @@ void launch_decode(const float *llr, const gr80211_frame_info *info, const int32
     else
         hipLaunchKernelGGL((k_decode<false, 1>), dim3(n_groups), dim3(64), 0, s, llr, info, slot_frame, groups, n_groups, dec,
                            bitsw, out, out_stride, out_len, n_pdu, bits_out, bits_stride, strict, totals);
+}
+void launch_decode_split2(const float *llr, const gr80211_frame_info *info, const int32_t *slot_frame, const GroupInfo *groups,
+                          int n_groups, uint32_t *dec, uint32_t *bitsw, uint8_t *out, int out_stride, int32_t *out_len,
+                          int32_t *n_pdu, uint8_t *bits_out, int bits_stride, int strict, const SchedTotals *totals, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_decode_split2, dim3(n_groups), dim3(128), 0, s, llr, info, slot_frame, groups, n_groups, dec, bitsw, out,
+                       out_stride, out_len, n_pdu, bits_out, bits_stride, strict, totals);
 }
 void launch_ndp_emit(const void *iq0, uint64_t arena_len, const gr80211_frame_desc *desc, int n,
                      const gr80211_frame_info *info, uint8_t *out, int out_stride, int32_t *out_len, int32_t *n_pdu,

@@ -180,13 +180,13 @@ def test_linearity_property_full_size(pkg, rxctx, oracle):
 
 @pytest.fixture(scope="module")
 def ctx_by_waves(pkg):
-    """Contexts pinned to 1 and 4 wavefronts per decoder group (by default the library chooses by batch size,
+    """Contexts pinned to 1, 2 and 4 wavefronts per decoder group (by default the library chooses by batch size,
     so the small batches of these tests would all take the four-wave path)."""
     import os
     made = {}
     old = os.environ.get("GR80211_GROUP_WAVES")
     try:
-        for w in (1, 4):
+        for w in (1, 2, 4):
             os.environ["GR80211_GROUP_WAVES"] = str(w)
             made[w] = pkg.RxContext(0)
     finally:
@@ -199,7 +199,7 @@ def ctx_by_waves(pkg):
         c.close()
 
 
-@pytest.mark.parametrize("waves", [1, 4])
+@pytest.mark.parametrize("waves", [1, 2, 4])
 def test_each_group_width_against_oracle(pkg, ctx_by_waves, oracle, waves):
     """Ragged lengths, all four code rates, integer LLRs with many ties: every way of spreading a group over
     wavefronts gives the oracle's bits and PDUs."""
@@ -216,7 +216,7 @@ def test_each_group_width_against_oracle(pkg, ctx_by_waves, oracle, waves):
 
 def test_group_widths_agree_bit_for_bit(pkg, ctx_by_waves):
     """A few thousand noisy frames (many groups, partly filled last groups per rate): survivor words written by 1
-    or 4 waves per group lead to identical decoded bits and PDU slots."""
+    2 or 4 waves per group lead to identical decoded bits and PDU slots."""
     import torch
     tx = pkg.txgen
     rx = pkg.rx
@@ -240,7 +240,7 @@ def test_group_widths_agree_bit_for_bit(pkg, ctx_by_waves):
         got[w] = (r["out"].cpu().numpy(), r["out_len"].cpu().numpy(), r["n_pdu"].cpu().numpy(), r["bits"].cpu().numpy())
     assert 0 < int(got[1][2].sum()) < n   # some frames fail the FCS, some pass
     valid = np.arange(768)[None, :] < got[1][1][:, None]   # the slots are uninitialised beyond out_len
-    for w in (4,):
+    for w in (2, 4):
         assert np.array_equal(got[1][1], got[w][1]) and np.array_equal(got[1][2], got[w][2]), w
         # decoded bits up to each frame's own trellis length (what lies beyond depends on the other frames that
         # happen to share its group)

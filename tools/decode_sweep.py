@@ -53,7 +53,7 @@ def main():
         frames.append(f)
     t0 = time.time()
     ok = {}
-    for waves in (1, 4):
+    for waves in (1, 2, 4):
         os.environ["GR80211_GROUP_WAVES"] = str(waves)
         ctx = pkg.RxContext(0)
         ok[str(waves)] = run_and_compare(pkg, ctx, O, frames)
