@@ -624,20 +624,22 @@ int decode::general_work(int, gr_vector_int &ninput_items, gr_vector_const_void_
     while (used < n) {
         if (d_state == S_IDLE) {
             const uint64_t at = r0 + (uint64_t)used;
-            get_tags_in_range(tags, 0, at, at + 1);
-            if (tags.empty()) {
+            // the packet's tags by value, without copying them (the last tag of a key wins, a missing one reads 99999)
+            static const char *const keys[7] = {"format", "len", "total", "cr", "mcs", "ampdu", "trellis"};
+            double v[7] = {DEFAULT_TAG, DEFAULT_TAG, DEFAULT_TAG, DEFAULT_TAG, DEFAULT_TAG, DEFAULT_TAG, DEFAULT_TAG};
+            if (!tag_values_at(0, at, keys, v, 7)) {
                 // The reference stays idle until an item carries tags (lib/decode_impl.cc:70-72,125-126);
                 // untagged items between packets are passed over here.
                 used = (int)(next_tag_offset(0, at + 1, r0 + (uint64_t)n) - r0);
                 continue;
             }
-            t_format = (long)tag_value(tags, "format", DEFAULT_TAG);
-            t_len = (long)tag_value(tags, "len", DEFAULT_TAG);
-            t_nTotal = (long)tag_value(tags, "total", DEFAULT_TAG);
-            t_cr = (long)tag_value(tags, "cr", DEFAULT_TAG);
-            t_mcs = (long)tag_value(tags, "mcs", DEFAULT_TAG);
-            t_ampdu = (long)tag_value(tags, "ampdu", DEFAULT_TAG);
-            v_trellis = (long)tag_value(tags, "trellis", DEFAULT_TAG);
+            t_format = (long)v[0];
+            t_len = (long)v[1];
+            t_nTotal = (long)v[2];
+            t_cr = (long)v[3];
+            t_mcs = (long)v[4];
+            t_ampdu = (long)v[5];
+            v_trellis = (long)v[6];
             t_nProcd = 0;
             d_nSeen++;
             if (t_nTotal <= 0) {  // a packet without items cannot be passed over by counting items
@@ -649,6 +651,7 @@ int decode::general_work(int, gr_vector_int &ninput_items, gr_vector_const_void_
             } else if (v_trellis == 0) {
                 // VHT NDP: the 2x1 channel dump travels as a message of its own (lib/decode_impl.cc:100-121)
                 d_state = S_CLEAN;
+                get_tags_in_range(tags, 0, at, at + 1);
                 const tag_t *ch = tag_find(tags, "mu2x1chan");
                 pdu_t m;
                 const int nbytes = (int)sizeof(float) * 256;
