@@ -2,6 +2,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <mutex>
 #include <utility>
 #include <string>
@@ -73,6 +74,7 @@ struct gr80211_ctx {
         bool used = false;
     } hstage[4];
     unsigned hstage_next = 0;
+    uint64_t pull_gen = 0;                  // state of the list of page-locked allocations the range below was taken from
     uintptr_t pull_lo = 0, pull_hi = 0;     // the page-locked range the last pull copy read from ...
     intptr_t pull_to_dev = 0;               // ... and what turns its host addresses into the GPU's
     static constexpr int N_MARK = 256;
@@ -481,6 +483,7 @@ struct HostRange {
 };
 std::mutex g_host_mutex;
 std::vector<HostRange> g_host_ranges;
+std::atomic<uint64_t> g_host_gen{1};  // bumped whenever the list changes: a context's remembered range is only good for one value
 
 bool host_range_of(const void *p, size_t bytes, HostRange *out)
 {
@@ -1135,10 +1138,12 @@ long long gr80211_pull_h2d(gr80211_ctx *c, void *d_dst, const void *h_src, size_
     // the last range that matched is tried first (a stream buffer is used call after call)
     void *dev_view = nullptr;
     const uintptr_t a = (uintptr_t)h_src;
-    if (!(a >= c->pull_lo && a + bytes <= c->pull_hi)) {
+    const uint64_t gen = g_host_gen.load(std::memory_order_acquire);
+    if (gen != c->pull_gen || !(a >= c->pull_lo && a + bytes <= c->pull_hi)) {
         HostRange r{0, 0, 0};
         (void)host_range_of(h_src, bytes, &r);
         c->pull_lo = r.lo, c->pull_hi = r.hi, c->pull_to_dev = r.to_dev;
+        c->pull_gen = gen;
     }
     if (c->pull_hi) {
         dev_view = (void *)(a + c->pull_to_dev);
@@ -1352,6 +1357,7 @@ void *gr80211_host_alloc(gr80211_ctx *c, size_t bytes)
     if (hipHostGetDevicePointer(&view, p, 0) == hipSuccess && view) {
         std::lock_guard<std::mutex> lk(g_host_mutex);
         g_host_ranges.push_back({(uintptr_t)p, (uintptr_t)p + (bytes ? bytes : 1), (intptr_t)((uintptr_t)view - (uintptr_t)p)});
+        g_host_gen.fetch_add(1, std::memory_order_release);
     } else {
         (void)hipGetLastError();
     }
@@ -1366,6 +1372,7 @@ void gr80211_host_free(gr80211_ctx *c, void *p)
         for (size_t i = 0; i < g_host_ranges.size(); i++)
             if (g_host_ranges[i].lo == (uintptr_t)p) {
                 g_host_ranges.erase(g_host_ranges.begin() + (long)i);
+                g_host_gen.fetch_add(1, std::memory_order_release);
                 break;
             }
     }
