@@ -20,9 +20,10 @@ PUMP = os.environ.get("GR80211_PUMP") or os.path.join(ROOT, "fork-gr-ieee80211_a
 ABI_CHAIN = os.environ.get("GR80211_ABI_CHAIN") or os.path.join(ROOT, "fork-gr-ieee80211_amd", "gr80211_abi_chain")
 
 
-def run_pump(args, prog=PUMP):
+def run_pump(args, prog=PUMP, env=None):
     assert os.path.exists(prog), "host blocks not built: run __graft_entry__.build()"
-    p = subprocess.run([prog] + [str(a) for a in args], capture_output=True, text=True, timeout=170)
+    p = subprocess.run([prog] + [str(a) for a in args], capture_output=True, text=True, timeout=170,
+                       env=dict(os.environ, **env) if env else None)
     assert p.returncode == 0, (p.returncode, p.stderr[-2000:])
     pdus = [bytes.fromhex(l.split()[1]) for l in p.stdout.splitlines() if l.startswith("PDU ")]
     stat = [l for l in p.stdout.splitlines() if l.startswith("STAT")]
@@ -90,6 +91,23 @@ def test_rx_block_siso_stream(tmp_path, oracle, chunk, batch):
     # every transmitted MPDU came back, in stream order
     mpdus = [p[3:-1] for p in got]
     assert mpdus == [f["mpdu"] for f in frames]
+
+
+@pytest.mark.parametrize("env", [{"GR80211_UPLOAD": "dma"}, {"GR80211_UPLOAD": "pull"},
+                                 {"GR80211_UPLOAD_STREAMS": "2", "GR80211_UPLOAD_SPLIT": "3"}, {"GR80211_PUMP_PIN": "0"},
+                                 {"GR80211_RX_MAX_HOLD": "20000", "GR80211_DECODE_MAX_HOLD": "5000"}])
+def test_rx_and_decode_blocks_whatever_way_the_windows_travel(tmp_path, pkg, rxctx, oracle, env):
+    """The streaming blocks give the same messages whether their windows go up by the runtime's copy engines, by the
+    copy kernel, by two upload streams in three pieces, synchronously from ordinary memory, or in rounds cut by the
+    sample limit instead of the frame count."""
+    iq0, triggers, frames = siso_stream(0.002, 6)
+    want, n_frames = model_chain(oracle, iq0, None, triggers)
+    tf, files = write_stream(tmp_path, iq0, None, triggers)
+    got, stat = run_pump(["rx", 1, 3000, 2, tf] + files, env=env)
+    assert got == want
+    tgf, lf, want_d, _, _ = decode_stream_files(tmp_path, pkg, rxctx, oracle)
+    got, stat = run_pump(["decode", 5000, 3, tgf, lf], env=env)
+    assert got == want_d
 
 
 class UdpListener:
@@ -192,9 +210,9 @@ def test_rx_block_reference_fixture(tmp_path, oracle):
     assert got[0][0] == 0 and got[0][-1] == 0  # legacy, 6 Mb/s
 
 
-@pytest.mark.parametrize("chunk,batch", [(4096, 1000), (1000, 2)])
-def test_decode_block_stream(tmp_path, pkg, rxctx, oracle, chunk, batch):
-    """decode drop-in: soft-bit stream with the tags demod attaches to a packet's first item."""
+def decode_stream_files(tmp_path, pkg, rxctx, oracle):
+    """The golden one-stream frames as the soft-bit stream `demod` hands to `decode` (tags on a packet's first item,
+    untagged items between packets, an oversize packet at the end): (tag file, soft-bit file, expected messages)."""
     import torch
     from util import build_arena
     frames = [f for f in golden_frames() if f["nss"] == 1]
@@ -226,9 +244,16 @@ def test_decode_block_stream(tmp_path, pkg, rxctx, oracle, chunk, batch):
     with open(tf, "w") as fh:
         for t in tags:
             fh.write(" ".join(str(v) for v in t) + "\n")
+    return tf, lf, want, len(tags), frames
+
+
+@pytest.mark.parametrize("chunk,batch", [(4096, 1000), (1000, 2)])
+def test_decode_block_stream(tmp_path, pkg, rxctx, oracle, chunk, batch):
+    """decode drop-in: soft-bit stream with the tags demod attaches to a packet's first item."""
+    tf, lf, want, n_tags, frames = decode_stream_files(tmp_path, pkg, rxctx, oracle)
     got, stat = run_pump(["decode", chunk, batch, tf, lf])
     assert got == want
-    assert "packets=%d " % len(tags) in stat + " ", stat
+    assert "packets=%d " % n_tags in stat + " ", stat
     assert [p[3:-1] for p in got] == [f["mpdu"] for f in frames]
 
 
