@@ -6,7 +6,9 @@
 One rank per GPU (torch.distributed / RCCL when N > 1; RANK, LOCAL_RANK, WORLD_SIZE, MASTER_* from the
 environment).  A step = one pass of the whole RX path (signal -> demod -> decode) over the rank's
 batch of frames, IQ already resident in HBM; for N > 1 the step ends with the gather of the decoded
-MPDUs on rank 0.  Rank 0 prints one JSON line.
+MPDUs on rank 0.  The timed steps rotate over two contexts per rank (--pipeline), queued by one host
+thread without a wait between them, so that one batch's decoder tail runs beside the next batch's front
+end; `one_batch_at_a_time` in the output is the same steps on one context.  Rank 0 prints one JSON line.
 
 Workload (default): BASELINE.json configs[2], the configuration the target is quoted on -- VHT MCS8
 (256-QAM r=3/4) SISO 20 MHz, 1500-byte A-MPDU (1496-byte MPDU), AWGN SNR 30 dB, 100 000 frames per GPU.
@@ -322,6 +324,9 @@ def main():
     ap.add_argument("--detect", action="store_true", help="also time frame detection over the raw capture")
     ap.add_argument("--host-buffers", action="store_true", help="also time one step with PCIe transfers included")
     ap.add_argument("--profile-steps", type=int, default=3, help="extra untimed steps with per-kernel HIP events")
+    ap.add_argument("--pipeline", type=int, default=2,
+                    help="contexts the timed steps rotate over (one host thread, nothing waited for between steps); "
+                         "1 = one batch at a time")
     ap.add_argument("--in-flight", type=int, default=2,
                     help="also time the same steps with this many batches in flight (one context, stream and host "
                          "thread each; N = 1 only; 1 = skip)")
@@ -366,8 +371,14 @@ def main():
     desc = torch.from_numpy(ctx.make_desc(sync, navail).view(np.uint8).reshape(-1)).to(dev)
     blob_len = exp.shape[1]
     out_stride = ((blob_len + 4 + 63) // 64) * 64
-    # two sets of outputs: at N > 1 the gather of one batch overlaps the kernels of the next
-    depth = 2 if world > 1 else 1
+    # The timed steps rotate over `pipe` contexts, each with its own stream, work buffers and output tensors: step k is
+    # queued on context k mod pipe without the host waiting for anything (GR80211_FLAG_NO_WAIT once the warm-up has
+    # sized the buffers), so the tail of one batch's decoder -- SIMDs that held one trellis fall idle before those that
+    # held two -- runs beside the next batch's preamble, demodulator and first decoder waves.  Every step is a whole
+    # pass over the whole batch; the steps differ only in where their results land.
+    pipe = max(1, args.pipeline)
+    depth = max(pipe, 2 if world > 1 else 1)
+    ctxs = [ctx] + [pkg.RxContext(local) for _ in range(pipe - 1)]
     outs = [(torch.zeros((n, out_stride), dtype=torch.uint8, device=dev),
              torch.zeros(n, dtype=torch.int32, device=dev),
              torch.zeros(n, dtype=torch.int32, device=dev)) for _ in range(depth)]
@@ -375,36 +386,32 @@ def main():
     shard = importlib.import_module("fork-gr-ieee80211_amd.shard")
     gatherer = shard.PduGather(n, out_stride, dev, dst=0, depth=depth) if world > 1 else None
     counter = [0]
+    no_wait = [False]
 
-    # At N > 1 the kernels and the collective share one explicit torch stream: the library launches on the stream it
-    # is handed (never on the context's own stream, whose order against the collective would only follow from the
-    # legacy default stream's implicit synchronisation), RCCL's gather is ordered behind whatever that stream holds
-    # when it is started, and wait() makes the same stream wait for the collective before a slot is reused.
-    side = torch.cuda.Stream(device=dev) if world > 1 else None
+    # Kernels and collective share a stream explicitly: every step runs under the torch view of its context's own
+    # stream (streams a context creates get hardware queues of their own; two from torch's pool were seen to share
+    # one), the library is handed that stream, RCCL's gather is ordered behind whatever the stream holds when it is
+    # started, and wait() makes the same stream wait for the collective before a slot's tensors are reused.
+    streams = [c.own_stream() for c in ctxs]
     gathered = [None]
 
     def step():
         slot = counter[0] % depth
         counter[0] += 1
         o, ol, npd = outs[slot]
-        if side is None:
-            ctx.rx_batch_into(arena, arena1, desc, n, o, ol, npd)
-            return
-        with torch.cuda.stream(side):
-            assert ctx._stream().value, "the library must be handed the side stream, not its own"
+        c = ctxs[slot % pipe]
+        with torch.cuda.stream(streams[slot % pipe]):
+            assert c._stream().value == c.lib.gr80211_get_stream(c.h), "the library must be handed the context's stream"
             if gatherer is not None:
-                gatherer.wait(slot)  # the batch that used these tensors two steps ago has left
-            ctx.rx_batch_into(arena, arena1, desc, n, o, ol, npd)
+                gatherer.wait(slot)  # the batch that used these tensors `depth` steps ago has left
+            c.rx_batch_into(arena, arena1, desc, n, o, ol, npd, no_wait=no_wait[0])
             if gatherer is not None:
                 # the one exchange step of the path: decoded MPDUs travel to rank 0 (RCCL gather over xGMI)
                 gatherer.start(slot, o, ol)
 
     def fence():
         if gatherer is not None:
-            if side is not None:
-                with torch.cuda.stream(side):
-                    last = gatherer.finish()
-            else:
+            with torch.cuda.stream(streams[0]):
                 last = gatherer.finish()
             if last[0] is not None:
                 gathered[0] = last
@@ -412,14 +419,18 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for _ in range(max(args.warmup, pipe)):  # every context's work buffers reach their size
         step()
     fence()
+    no_wait[0] = True
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     fence()
     dt = time.perf_counter() - t0
+    refused = [c.last_batch_refused() for c in ctxs]
+    if any(refused):
+        raise RuntimeError("a batch queued without the wait found too little room: %r" % (refused,))
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -467,12 +478,28 @@ def main():
                         "note": "the PDU slots rank 0 holds after the last gather of the timed region, "
                                 "compared with the MPDUs each rank's corpus was generated from"}
 
-    # ---- correctness of what was just timed
+    # ---- correctness of what was just timed: the results of the last step of every context (the first set is the one
+    # reported; the others must not differ from it)
     n_ok = int(n_pdu.sum().item())
     ok_rows = (n_pdu == 1)
     match = (out[:, :blob_len] == exp[idx]).all(dim=1)
     bitexact = int((match & ok_rows).sum().item())
     wrong = int((ok_rows & ~match).sum().item())
+    for o2, ol2, np2 in outs[1:min(depth, max(args.warmup, pipe) + args.steps)]:
+        if not (torch.equal(np2, n_pdu) and torch.equal(ol2, out_len) and torch.equal(o2[:, :blob_len], out[:, :blob_len])):
+            raise RuntimeError("the contexts of the pipeline disagree about the same batch")
+
+    # ---- the same steps one batch at a time (one context, each step queued behind the one before): the figure the
+    # pipelined rate is to be compared with
+    serial_ms = None
+    if pipe > 1:
+        fence()
+        t1 = time.perf_counter()
+        with torch.cuda.stream(streams[0]):
+            for _ in range(args.steps):
+                ctx.rx_batch_into(arena, arena1, desc, n, out, out_len, n_pdu)
+        fence()
+        serial_ms = (time.perf_counter() - t1) / args.steps * 1e3
 
     # ---- the same steps with several batches in flight: one context per batch, each on the stream it created (these
     # land on hardware queues of their own; streams from torch's pool were seen to share one), one host thread each.
@@ -482,7 +509,7 @@ def main():
         try:
             import threading
             depth_f = args.in_flight
-            ctxs = [ctx] + [pkg.RxContext(local) for _ in range(depth_f - 1)]
+            fctxs = [ctx] + [pkg.RxContext(local) for _ in range(depth_f - 1)]
             fouts = [(out, out_len, n_pdu)] + [tuple(torch.zeros_like(t) for t in (out, out_len, n_pdu))
                                                 for _ in range(depth_f - 1)]
             errors = []
@@ -494,8 +521,8 @@ def main():
                     if delay > 0:
                         time.sleep(delay)
                     for _ in range(steps):
-                        ctxs[k].rx_batch_into(arena, arena1, desc, n, *fouts[k])
-                    ctxs[k].sync()
+                        fctxs[k].rx_batch_into(arena, arena1, desc, n, *fouts[k])
+                    fctxs[k].sync()
                 except Exception as e:  # noqa: BLE001 - reported from the main thread
                     errors.append(repr(e))
 
@@ -520,9 +547,9 @@ def main():
                 exact.append([int(rows.sum().item()), int((rows & m).sum().item()), int((rows & ~m).sum().item())])
             in_flight = {"contexts": depth_f, "steps": per * depth_f, "ms_per_step": dtf / (per * depth_f) * 1e3,
                          "fcs_ok__bit_exact__wrong_per_context": exact}
-            for c in ctxs[1:]:
+            for c in fctxs[1:]:
                 c.close()
-            del fouts, ctxs
+            del fouts, fctxs
         except Exception as e:  # noqa: BLE001 - this leg is an extra: the headline line is printed whatever happens here
             in_flight = {"error": repr(e)}
 
@@ -551,10 +578,16 @@ def main():
                    "psdu_bytes": nbytes + 4 if fmt == 2 else nbytes, "snr_db": snr_db, "unique_payloads": args.unique if args.unique > 0 else n,
                    "parallelism": ("frames sharded per rank, gather of MPDUs to rank 0 over %s" %
                                    ("RCCL" if backend == "nccl" else backend + " (host-staged rehearsal, ranks share GPUs)"))
-                   if world > 1 else "single GPU"},
+                   if world > 1 else "single GPU",
+                   "batches_in_flight": pipe},
         "psdu": {"frames": n, "fcs_ok": n_ok, "bit_exact_vs_tx": bitexact, "fcs_ok_but_wrong": wrong},
         "kernel_ms": timing,
     }
+    if serial_ms is not None:
+        res["one_batch_at_a_time"] = {"ms_per_step": serial_ms, "value": samples_per_step / serial_ms / 1e3,
+                                      "unit": "Msamples/s",
+                                      "note": "the same steps on one context per rank, each queued behind the one before, "
+                                              "no exchange; `value` above rotates its steps over %d contexts" % pipe}
     if gather_check is not None:
         res["gathered_on_rank0"] = gather_check
     if value_local is not None:

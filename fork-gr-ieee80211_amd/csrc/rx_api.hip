@@ -648,6 +648,8 @@ int gr80211_sync(gr80211_ctx *c, void *stream)
     return GR80211_OK;
 }
 
+void *gr80211_get_stream(gr80211_ctx *c) { return c ? (void *)c->stream : nullptr; }
+
 int gr80211_rx_batch(gr80211_ctx *c, const void *d_iq0, const void *d_iq1, uint64_t arena_len,
                      const gr80211_frame_desc *desc, int n, unsigned flags, uint8_t *d_out, int out_stride,
                      int32_t *d_out_len, int32_t *d_n_pdu, gr80211_frame_info *d_info, void *stream)

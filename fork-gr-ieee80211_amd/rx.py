@@ -73,7 +73,7 @@ EXPORTS = [
     "gr80211_version", "gr80211_table_checksum", "gr80211_tx_samples", "gr80211_tx_batch", "gr80211_set_mu_pos", "gr80211_set_ampdu_strict", "gr80211_tx_mu_batch",
     "gr80211_host_alloc", "gr80211_host_free", "gr80211_copy_d2d", "gr80211_signal_emit_batch", "gr80211_demod_tagged_batch",
     "gr80211_rx_submit", "gr80211_rx_finish", "gr80211_decode_batch_noalloc", "gr80211_rx_resume",
-    "gr80211_last_batch_refused", "gr80211_copy_h2d_async", "gr80211_copy_d2h_async", "gr80211_copy_d2d_async", "gr80211_pull_h2d", "gr80211_pull_done", "gr80211_push_d2h",
+    "gr80211_last_batch_refused", "gr80211_copy_h2d_async", "gr80211_copy_d2h_async", "gr80211_copy_d2d_async", "gr80211_pull_h2d", "gr80211_pull_done", "gr80211_push_d2h", "gr80211_get_stream",
     "gr80211_stream_idle", "gr80211_stream_wait", "gr80211_marker_record", "gr80211_marker_done",
     "gr80211_host_register", "gr80211_host_unregister",
 ]
@@ -116,6 +116,8 @@ def load_library():
     L.gr80211_pull_h2d.restype = C.c_longlong
     L.gr80211_pull_done.argtypes = [vp, C.c_longlong, C.c_int]
     L.gr80211_push_d2h.argtypes = [vp, vp, vp, C.c_size_t, vp]
+    L.gr80211_get_stream.argtypes = [vp]
+    L.gr80211_get_stream.restype = vp
     L.gr80211_stream_idle.argtypes = [vp, vp]
     L.gr80211_stream_wait.argtypes = [vp, vp, vp, vp]
     L.gr80211_marker_record.argtypes = [vp, vp]
@@ -198,6 +200,13 @@ class RxContext:
     def _check(self, rc, what):
         if rc != 0:
             raise RuntimeError("%s failed (%d): %s" % (what, rc, self.lib.gr80211_last_error(self.h).decode()))
+
+    def own_stream(self):
+        """The context's own HIP stream as a torch stream (torch.cuda.ExternalStream): work queued under
+        `with torch.cuda.stream(ctx.own_stream())` -- this library's calls, torch kernels, collectives -- shares it."""
+        if getattr(self, "_own", None) is None:
+            self._own = self.torch.cuda.ExternalStream(self.lib.gr80211_get_stream(self.h), device=self.dev)
+        return self._own
 
     def _stream(self):
         return C.c_void_p(self.torch.cuda.current_stream(self.dev).cuda_stream)

@@ -166,6 +166,12 @@ int gr80211_create(gr80211_ctx **out, int device);
 void gr80211_destroy(gr80211_ctx *ctx);
 const char *gr80211_last_error(gr80211_ctx *ctx);
 int gr80211_sync(gr80211_ctx *ctx, void *stream);
+/*
+ * The HIP stream the context created for itself (what every call uses when it is handed stream == NULL), as a
+ * hipStream_t: for a caller that wants other work (a collective, its own kernels) ordered on it.  Streams a context
+ * creates get hardware queues of their own, which streams taken from another library's pool may not.
+ */
+void *gr80211_get_stream(gr80211_ctx *ctx);
 
 /*
  * Whole RX path for a batch of independent frames: the work of

@@ -2,7 +2,7 @@
 # Collects the evidence kept under profiles/: the bench line, the rocprofv3 kernel-trace statistics of the same
 # command, and the counter passes (one rocprofv3 --pmc run each: HBM traffic, vector-instruction issue, clock).  The
 # profiled runs take `--in-flight 1`: the batches_in_flight leg of the default command runs kernels of two contexts
-# side by side, which stretches every launch and would blur the per-launch averages the roofline figure is checked
+# side by side, as do the timed steps of the default command (two contexts in rotation), which stretches every launch and would blur the per-launch averages the roofline figure is checked
 # against.  Run on the GPU box from the repository root:
 #   bash tools/profile_round.sh <tag> [bench.py options]
 set -u
@@ -14,13 +14,13 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 cd "$ROOT"
 echo "[profile_round] bench"; timeout -k 10 400 python3 bench.py --steps 5 --warmup 2 "$@" > "$OUT/bench.log" 2>"$OUT/bench.err" || exit 1
-echo "[profile_round] kernel trace"; timeout -k 10 300 rocprofv3 --kernel-trace --stats -d "$OUT/kt" -o kt -- python3 bench.py --steps 5 --warmup 2 --cpu-frames 0 --profile-steps 0 --in-flight 1 "$@" > "$OUT/kt.log" 2>&1 || exit 2
+echo "[profile_round] kernel trace"; timeout -k 10 300 rocprofv3 --kernel-trace --stats -d "$OUT/kt" -o kt -- python3 bench.py --steps 5 --warmup 2 --cpu-frames 0 --profile-steps 0 --in-flight 1 --pipeline 1 "$@" > "$OUT/kt.log" 2>&1 || exit 2
 python3 tools/rocpd_summary.py "$OUT"/kt/kt_results.db > "$OUT/kernel_stats.txt" 2>&1
 rm -rf "$OUT/kt"
 pass() {  # <name> <counters...>
     local name=$1; shift
     echo "[profile_round] pmc pass $name: $*"
-    timeout -s KILL 300 rocprofv3 --kernel-trace --pmc "$@" -d "$OUT/p_$name" -o p -- python3 bench.py --steps 1 --warmup 0 --cpu-frames 0 --profile-steps 0 --in-flight 1 $BENCH_EXTRA > "$OUT/p_$name.log" 2>&1 || return 1
+    timeout -s KILL 300 rocprofv3 --kernel-trace --pmc "$@" -d "$OUT/p_$name" -o p -- python3 bench.py --steps 1 --warmup 0 --cpu-frames 0 --profile-steps 0 --in-flight 1 --pipeline 1 $BENCH_EXTRA > "$OUT/p_$name.log" 2>&1 || return 1
     python3 tools/rocpd_summary.py "$OUT/p_$name"/p_results.db > "$OUT/pmc_$name.txt" 2>&1
     rm -rf "$OUT/p_$name"
 }
