@@ -497,9 +497,11 @@ def main():
         t1 = time.perf_counter()
         with torch.cuda.stream(streams[0]):
             for _ in range(args.steps):
-                ctx.rx_batch_into(arena, arena1, desc, n, out, out_len, n_pdu)
+                ctx.rx_batch_into(arena, arena1, desc, n, out, out_len, n_pdu, no_wait=True)
         fence()
         serial_ms = (time.perf_counter() - t1) / args.steps * 1e3
+        if ctx.last_batch_refused():
+            raise RuntimeError("a batch queued without the wait found too little room")
 
     # ---- the same steps with several batches in flight: one context per batch, each on the stream it created (these
     # land on hardware queues of their own; streams from torch's pool were seen to share one), one host thread each.
