@@ -842,9 +842,9 @@ const size_t MAX_SPAN = 224 + 80 * ((4095 * 8 + 22 + 23) / 24);
 
 rx::sptr rx::make(int n_rx, int batch_frames, int device) { return sptr(new rx(n_rx, batch_frames, device)); }
 
-rx::rx(int n_rx, int batch_frames, int device, int n_out)
-    : block(n_rx == 2 ? 3 : 2, n_out), d_nrx(n_rx == 2 ? 2 : 1), d_batch(batch_frames < 1 ? 1 : batch_frames), d_up(device),
-      d_maxHold((size_t)1 << 24)
+rx::rx(int n_rx, int batch_frames, int device, int n_out, bool sync_port)
+    : block((n_rx == 2 ? 2 : 1) + (sync_port ? 1 : 0), n_out), d_nrx(n_rx == 2 ? 2 : 1), d_batch(batch_frames < 1 ? 1 : batch_frames),
+      d_port0(sync_port ? 1 : 0), d_up(device), d_maxHold((size_t)1 << 24)
 {
     if (!d_up.ok()) {
         d_err = "gr80211_create failed";
@@ -1013,7 +1013,7 @@ int rx::take_input(gr_vector_int &ninput_items, gr_vector_const_void_star &input
             const char *src[2];
             char *dst[2];
             for (int a = 0; a < d_nrx; a++) {
-                src[a] = reinterpret_cast<const char *>(static_cast<const gr_complex *>(input_items[1 + a]) + from);
+                src[a] = reinterpret_cast<const char *>(static_cast<const gr_complex *>(input_items[d_port0 + a]) + from);
                 dst[a] = f.iq[a] + f.n * sizeof(gr_complex);
                 pinned = pinned && is_pinned(src[a], cnt * sizeof(gr_complex));
             }
@@ -1052,6 +1052,7 @@ bool rx::cut(bool final)
         d_err = r.gpu->error();
         return false;
     }
+    if (!before_cut(r, final)) return false;
     round *nx = nullptr;
     if (!final) {
         nx = free_round();
@@ -1066,8 +1067,9 @@ bool rx::cut(bool final)
         nx->n_new = 0;
         nx->n = 0;
         nx->base = end;
-        if (!nx->trig.empty()) {
-            const uint64_t from = std::max(nx->trig[0].pos, r.base);
+        if (!nx->trig.empty() || d_carryBack) {
+            uint64_t from = nx->trig.empty() ? end : std::max(nx->trig[0].pos, r.base);
+            if (d_carryBack) from = std::min(from, end > r.base + d_carryBack ? end - d_carryBack : r.base);
             const size_t cnt = (size_t)(end - from);
             if (!reserve(*nx, cnt)) {
                 d_err = "device memory for the held samples exhausted";
@@ -1553,14 +1555,10 @@ bool demod::run_batch()
 // ------------------------------------------------------------------------------------ capture_rx
 capture_rx::sptr capture_rx::make(int n_rx, int device) { return sptr(new capture_rx(n_rx, device)); }
 
-capture_rx::capture_rx(int n_rx, int device)
-    : block(n_rx == 2 ? 2 : 1), d_nrx(n_rx == 2 ? 2 : 1), d_gpu(device), d_hold0(d_gpu, sizeof(gr_complex)),
-      d_hold1(d_gpu, sizeof(gr_complex))
+capture_rx::capture_rx(int n_rx, int device) : rx(n_rx, 1 << 30, device, 0, false)
 {
-    if (!d_gpu.ok()) d_err = "gr80211_create failed";
+    d_carryBack = DET_MARGIN + DET_HISTORY;
 }
-
-capture_rx::~capture_rx() { unpin_all(); }
 
 void capture_rx::forecast(int noutput_items, gr_vector_int &ninput_items_required)
 {
@@ -1569,57 +1567,90 @@ void capture_rx::forecast(int noutput_items, gr_vector_int &ninput_items_require
 
 int capture_rx::general_work(int, gr_vector_int &ninput_items, gr_vector_const_void_star &input_items, gr_vector_void_star &)
 {
+    consume_each(0);
+    if (!d_err.empty()) return 0;
     int n = ninput_items[0];
     if (d_nrx == 2) n = std::min(n, ninput_items[1]);
-    for (int a = 0; a < d_nrx; a++) {
-        const gr_complex *s = static_cast<const gr_complex *>(input_items[a]);
-        if (!hold(a).append(s, (size_t)n)) {
-            d_err = "upload of the samples failed: " + d_gpu.error();
-            consume_each(0);
-            return 0;
+    const uint64_t r0 = nitems_read(0);
+    upload_log &log = d_up.log();
+    if (log.enqueued() < r0) log.set_enqueued(r0);
+    if (!d_flight.empty() && poll_due(d_lastPoll) && !advance(false, false)) return 0;
+    // items [lo, n) of the window are new; every one of them goes to the round being filled
+    int lo = (int)std::min<uint64_t>(log.enqueued() - r0, (uint64_t)n);
+    while (lo < n) {
+        round &f = *d_fill;
+        if (f.n == 0) f.base = r0 + (uint64_t)lo;
+        // a round ends exactly at its limit, so that the rounds of a stream do not depend on the windows it came in
+        const size_t room = f.n < d_maxHold ? d_maxHold - f.n : 0;
+        const size_t cnt = std::min<size_t>((size_t)(n - lo), room);
+        if (cnt > 0) {
+            if (!reserve(f, f.n + cnt)) {
+                d_err = "device memory for the held samples exhausted";
+                return 0;
+            }
+            bool pinned = true;
+            const char *src[2];
+            char *dst[2];
+            for (int a = 0; a < d_nrx; a++) {
+                src[a] = reinterpret_cast<const char *>(static_cast<const gr_complex *>(input_items[a]) + lo);
+                dst[a] = f.iq[a] + f.n * sizeof(gr_complex);
+                pinned = pinned && is_pinned(src[a], cnt * sizeof(gr_complex));
+            }
+            if (!d_up.send(*f.gpu, d_nrx, src, dst, cnt, sizeof(gr_complex), r0 + (uint64_t)lo, pinned, d_err)) return 0;
+            f.n += cnt;
+            lo += (int)cnt;
+        }
+        if (f.n >= d_maxHold && !cut(false)) return 0;
+    }
+    log.set_enqueued(r0 + (uint64_t)n);
+    consume_each((int)(log.settled(r0) - r0));
+    return 0;
+}
+
+// The round's sync bytes: frame detection over its samples (antenna 1, as in the reference flowgraphs).  Sync bytes
+// before d_detFrom were taken by the round before; those within DET_MARGIN of the end are left to the next round,
+// which sees the samples that follow them.
+bool capture_rx::before_cut(round &r, bool final)
+{
+    if (r.n == 0) return true;
+    gr80211_ctx *c = r.gpu->ctx();
+    const uint64_t end = r.base + r.n;
+    const int max_desc = (int)std::min<size_t>(r.n / 80 + 16, (size_t)1 << 20);
+    gr80211_frame_desc *dd = static_cast<gr80211_frame_desc *>(r.gpu->buffer(6, (size_t)max_desc * sizeof(gr80211_frame_desc)));
+    int nd = 0;
+    if (!dd || gr80211_detect(c, r.iq[0], r.n, dd, max_desc, &nd, nullptr) != GR80211_OK) {
+        d_err = "frame detection failed: " + r.gpu->error();
+        return false;
+    }
+    const uint64_t upto = final || end < DET_MARGIN ? end : end - DET_MARGIN;
+    if (nd > 0) {
+        gr80211_frame_desc *hd = static_cast<gr80211_frame_desc *>(r.gpu->staging(3, (size_t)nd * sizeof(gr80211_frame_desc)));
+        if (!hd || gr80211_copy_d2h(c, hd, dd, (size_t)nd * sizeof(gr80211_frame_desc), nullptr) != GR80211_OK) {
+            d_err = "frame detection failed: " + r.gpu->error();
+            return false;
+        }
+        for (int i = 0; i < nd; i++) {
+            const uint64_t pos = r.base + hd[i].sync_off;
+            if (pos < d_detFrom || pos >= upto) continue;
+            trigger t;
+            t.pos = pos;
+            t.rad = hd[i].rad;
+            t.snr = hd[i].snr;
+            t.rssi = hd[i].rssi;
+            r.trig.push_back(t);
+            r.n_new++;
+            d_nSync++;
+            d_nTrig++;
         }
     }
-    consume_each(n);
-    return 0;
+    d_detFrom = upto;
+    return true;
 }
 
 bool capture_rx::flush()
 {
-    const size_t n = d_hold0.size();
-    if (n == 0) return true;
-    if (!d_gpu.ok()) return false;
-    gr80211_ctx *c = d_gpu.ctx();
-    const void *diq0 = d_hold0.data();
-    const void *diq1 = d_nrx == 2 ? d_hold1.data() : nullptr;
-    // a frame needs at least 400 samples of preamble; sync bytes whose L-SIG check fails also take a slot
-    const int max_frames = (int)std::min<size_t>(n / 80 + 16, (size_t)1 << 20);
-    uint8_t *dout = static_cast<uint8_t *>(d_gpu.buffer(3, (size_t)max_frames * OUT_STRIDE));
-    int32_t *dlen = static_cast<int32_t *>(d_gpu.buffer(4, (size_t)max_frames * 4));
-    int32_t *dnp = static_cast<int32_t *>(d_gpu.buffer(5, (size_t)max_frames * 4));
-    if (!dout || !dlen || !dnp) {
-        d_err = "device allocation failed";
-        return false;
-    }
-    int nf = 0;
-    if (gr80211_set_mu_pos(c, d_muPos) != GR80211_OK ||
-        gr80211_rx_capture(c, diq0, diq1, n, dout, OUT_STRIDE, dlen, dnp, max_frames, nullptr, &nf, nullptr) != GR80211_OK) {
-        d_err = d_gpu.error();
-        return false;
-    }
-    uint8_t *out = static_cast<uint8_t *>(d_gpu.staging(0, (size_t)nf * OUT_STRIDE + 1));
-    int32_t *len = static_cast<int32_t *>(d_gpu.staging(1, (size_t)nf * 4 + 4));
-    if (!out || !len) {
-        d_err = "page-locked host memory exhausted";
-        return false;
-    }
-    if (nf > 0 && (gr80211_copy_d2h(c, len, dlen, (size_t)nf * 4, nullptr) != GR80211_OK ||
-                   gr80211_copy_d2h(c, out, dout, (size_t)nf * OUT_STRIDE, nullptr) != GR80211_OK)) {
-        d_err = d_gpu.error();
-        return false;
-    }
-    d_nFrames += (uint64_t)nf;
-    d_nPdu += publish_slots(out, len, nf, OUT_STRIDE);
-    for (int a = 0; a < d_nrx; a++) hold(a).clear();
+    if (!rx::flush()) return false;
+    d_detFrom = 0;  // another stream starts from nothing
     return true;
 }
 

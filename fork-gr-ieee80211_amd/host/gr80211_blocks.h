@@ -363,7 +363,8 @@ public:
     uint64_t rounds_cut() const { return d_nRounds; }
 
 protected:
-    rx(int n_rx, int batch_frames, int device, int n_out = 0);
+    // sync_port: input 0 is the sync byte stream (false: the antenna streams only, for capture_rx)
+    rx(int n_rx, int batch_frames, int device, int n_out = 0, bool sync_port = true);
     gr80211_ctx *pin_context() override { return d_up.session().ctx(); }
     struct frame_ref {
         uint64_t pos;  // absolute item index of the trigger byte
@@ -398,6 +399,9 @@ protected:
     // (nothing waited for) and publishes them in finish_frames once the round's stream has run dry.
     virtual bool start_frames(round &r);
     virtual bool finish_frames(round &r);
+    // Called by cut() once the round's samples are all behind its stream: a block that finds the round's sync bytes
+    // itself adds them to r.trig here (capture_rx).  final: the stream ends with this round.
+    virtual bool before_cut(round &, bool /*final*/) { return true; }
     int take_input(gr_vector_int &ninput_items, gr_vector_const_void_star &input_items);  // items consumed, -1 on error
     bool cut(bool final);
     bool advance(bool wait_front, bool wait_all);
@@ -406,6 +410,8 @@ protected:
     round *free_round();
 
     int d_nrx, d_batch;
+    int d_port0 = 1;                    // input port of the first antenna (1 behind a sync port, else 0)
+    size_t d_carryBack = 0;             // samples before a round's end that the next round always gets again
     int d_muPos = 0;
     uploader d_up;                      // the samples' way to the arenas of the round being filled
     static constexpr int N_ROUNDS = 3;
@@ -487,38 +493,34 @@ private:
     uint64_t d_nSeen = 0;
 };
 
-// Whole receive flowgraph of examples/rx.grc / rx2.grc for a recorded capture: inputs are the antenna streams only
-// ({c64} or {c64, c64}); presiso -> trigger -> sync -> signal(2) -> demod(2) -> decode run on the GPU in one call
-// (gr80211_rx_capture) when the stream ends.  general_work only collects samples: detection keeps state across
-// the whole stream (plateaus, countdowns, the 111 items sync skips), so a capture is processed in one piece.
-class capture_rx : public block
+// Whole receive flowgraph of examples/rx.grc / rx2.grc: inputs are the antenna streams only ({c64} or {c64, c64});
+// presiso -> trigger -> sync -> signal(2) -> demod(2) -> decode all run on the GPU.  It is the fused rx block with
+// the sync bytes found by gr80211_detect instead of read from a port: the stream is cut into rounds of set_max_hold
+// samples, every round's samples are searched for sync bytes when it is cut, and from there on a round goes the way
+// of rx (probe, trigger search, decode, publish).  Detection keeps state for a few hundred samples (plateaus,
+// countdowns, the 111 items sync skips, 64-sample correlations), so a round takes the sync bytes up to 1024 samples
+// before its end and leaves the rest to the next round, which starts another 1024 samples earlier.
+class capture_rx : public rx
 {
 public:
     typedef std::shared_ptr<capture_rx> sptr;
     static sptr make(int n_rx = 1, int device = 0);
-    ~capture_rx() override;
 
     void forecast(int noutput_items, gr_vector_int &ninput_items_required) override;
     int general_work(int noutput_items, gr_vector_int &ninput_items, gr_vector_const_void_star &input_items,
                      gr_vector_void_star &output_items) override;
     bool flush() override;
-
-    void set_mu_pos(int pos) { d_muPos = pos ? 1 : 0; }
-    void set_ampdu_strict(bool on) { d_gpu.set_ampdu_strict(on); }
-    uint64_t frames_decoded() const { return d_nFrames; }
-    uint64_t pdus_published() const { return d_nPdu; }
+    uint64_t sync_bytes_found() const { return d_nSync; }
 
 protected:
-    gr80211_ctx *pin_context() override { return d_gpu.ctx(); }
+    bool before_cut(round &r, bool final) override;
 
 private:
     capture_rx(int n_rx, int device);
-    int d_nrx;
-    int d_muPos = 0;
-    gpu_session d_gpu;
-    device_fifo d_hold0, d_hold1;
-    device_fifo &hold(int a) { return a ? d_hold1 : d_hold0; }
-    uint64_t d_nFrames = 0, d_nPdu = 0;
+    static constexpr size_t DET_MARGIN = 1024;   // a round leaves the sync bytes of its last samples to the next round
+    static constexpr size_t DET_HISTORY = 1024;  // samples the next round gets before the first one it searches
+    uint64_t d_detFrom = 0;                      // absolute index from which sync bytes are still to be taken
+    uint64_t d_nSync = 0;
 };
 
 }  // namespace host

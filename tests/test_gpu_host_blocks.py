@@ -270,6 +270,45 @@ def test_capture_block_raw_stream(tmp_path, oracle):
     assert "frames=%d " % model_chain.dealt_with in stat + " ", stat
 
 
+@pytest.mark.parametrize("hold", [438016, 700001])
+def test_capture_block_in_rounds_equals_the_whole_capture(tmp_path, pkg, rxctx, hold):
+    """capture_rx cuts a long stream into rounds and finds each round's sync bytes when it cuts it; the messages are
+    those of gr80211_rx_capture over the whole stream at once, whatever the round length and the windows (frames of
+    mixed formats and lengths with gaps of noise between them, so that round ends fall inside preambles, payloads
+    and gaps alike)."""
+    import torch
+    tx = pkg.txgen
+    rng = np.random.default_rng(71)
+    parts = []
+    for k in range(420):
+        fmt = int(rng.integers(0, 3))
+        mcs = int(rng.integers(0, 8 if fmt < 2 else 9))
+        iq, _ = tx.gen_frame(fmt, mcs, 1, tx.make_mpdu(int(rng.integers(40, 1500)), rng))
+        parts.append(np.zeros(int(rng.integers(200, 1200)), np.complex64))
+        parts.append(np.asarray(iq[0] * 12.0, np.complex64))
+    parts.append(np.zeros(600, np.complex64))
+    iq0 = np.concatenate(parts)
+    sigma = np.sqrt(np.mean(np.abs(parts[1]) ** 2) / 2) * 10 ** (-35.0 / 20)  # 35 dB below the frames
+    iq0 = (iq0 + sigma * (rng.standard_normal(len(iq0)) + 1j * rng.standard_normal(len(iq0)))).astype(np.complex64)
+    assert len(iq0) > 3 * hold
+    whole = rxctx.rx_capture(torch.from_numpy(iq0).cuda(), None, max_frames=2000)
+    rxctx.sync()
+    nf = whole["n"]
+    lens = whole["out_len"][:nf].cpu().numpy()
+    rows = whole["out"][:nf].cpu().numpy()
+    want = []
+    for i in range(nf):
+        want += [blob_of(p) for p in pkg.rx.split_pdus(bytes(rows[i, : lens[i]]))]
+    assert len(want) >= 400, (nf, len(want))
+    f0 = tmp_path / "iq0.bin"
+    iq0.tofile(f0)
+    for chunk in (65536, 7001):
+        got, stat = run_pump(["capture", 1, chunk, f0], env={"GR80211_RX_MAX_HOLD": str(hold)})
+        bad = [i for i in range(min(len(got), len(want))) if got[i] != want[i]]
+        assert got == want, (chunk, len(got), len(want), bad[:10], [len(got[i]) for i in bad[:5]], [len(want[i]) for i in bad[:5]])
+        assert "frames=%d " % nf in stat + " ", stat
+
+
 def test_rx_block_publishes_ndp_channel(tmp_path, oracle):
     """A sounding NDP in the stream: the block publishes the 1027-byte channel message (no mcs byte) between the
     data frames' PDUs."""
