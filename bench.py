@@ -6,7 +6,7 @@
 One rank per GPU (torch.distributed / RCCL when N > 1; RANK, LOCAL_RANK, WORLD_SIZE, MASTER_* from the
 environment).  A step = one pass of the whole RX path (signal -> demod -> decode) over the rank's
 batch of frames, IQ already resident in HBM; for N > 1 the step ends with the gather of the decoded
-MPDUs on rank 0.  The timed steps rotate over two contexts per rank (--pipeline), queued by one host
+MPDUs on rank 0.  The timed steps rotate over three contexts per rank (--pipeline), queued by one host
 thread without a wait between them, so that one batch's decoder tail runs beside the next batch's front
 end; `one_batch_at_a_time` in the output is the same steps on one context.  Rank 0 prints one JSON line.
 
@@ -314,8 +314,8 @@ MIX_FLOOR_CYCLES = 14.6
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames", type=int, default=0, help="frames per GPU (0 = the workload's configured size)")
     ap.add_argument("--workload", default="vht_mcs8_1500B_snr30", choices=sorted(WORKLOADS) + [MIXED])
     ap.add_argument("--unique", type=int, default=0,
@@ -324,7 +324,7 @@ def main():
     ap.add_argument("--detect", action="store_true", help="also time frame detection over the raw capture")
     ap.add_argument("--host-buffers", action="store_true", help="also time one step with PCIe transfers included")
     ap.add_argument("--profile-steps", type=int, default=3, help="extra untimed steps with per-kernel HIP events")
-    ap.add_argument("--pipeline", type=int, default=2,
+    ap.add_argument("--pipeline", type=int, default=3,
                     help="contexts the timed steps rotate over (one host thread, nothing waited for between steps); "
                          "1 = one batch at a time")
     ap.add_argument("--in-flight", type=int, default=2,

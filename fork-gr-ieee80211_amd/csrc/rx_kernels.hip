@@ -1803,13 +1803,13 @@ int read_timeline(unsigned long long *dst, int n_groups)
 constexpr int DEC_WAVES = 4;
 
 template <bool TWO_TILES, int WAVES>
-__global__ __launch_bounds__(64 * WAVES) void k_decode(const float *__restrict__ llr, const gr80211_frame_info *__restrict__ info,
-                                               const int32_t *__restrict__ slot_frame,
-                                               const GroupInfo *__restrict__ groups, int n_groups,
-                                               uint32_t *__restrict__ dec, uint32_t *__restrict__ bitsw,
-                                               uint8_t *__restrict__ out, int out_stride, int32_t *__restrict__ out_len,
-                                               int32_t *__restrict__ n_pdu, uint8_t *__restrict__ bits_out, int bits_stride,
-                                               int strict, const SchedTotals *__restrict__ totals)
+__device__ __forceinline__ void decode_wave(const float *__restrict__ llr, const gr80211_frame_info *__restrict__ info,
+                                            const int32_t *__restrict__ slot_frame,
+                                            const GroupInfo *__restrict__ groups, int n_groups,
+                                            uint32_t *__restrict__ dec, uint32_t *__restrict__ bitsw,
+                                            uint8_t *__restrict__ out, int out_stride, int32_t *__restrict__ out_len,
+                                            int32_t *__restrict__ n_pdu, uint8_t *__restrict__ bits_out, int bits_stride,
+                                            int strict, const SchedTotals *__restrict__ totals)
 {
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g0 = blockIdx.x * WAVES + wv;
@@ -1852,6 +1852,32 @@ __global__ __launch_bounds__(64 * WAVES) void k_decode(const float *__restrict__
 #ifdef GR80211_TIMELINE
     if (lane == 0 && g < 8192) g_timeline[4 * g + 2] = wall_clock64();
 #endif
+}
+
+template <bool TWO_TILES, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void k_decode(const float *__restrict__ llr, const gr80211_frame_info *__restrict__ info,
+                                               const int32_t *__restrict__ slot_frame,
+                                               const GroupInfo *__restrict__ groups, int n_groups,
+                                               uint32_t *__restrict__ dec, uint32_t *__restrict__ bitsw,
+                                               uint8_t *__restrict__ out, int out_stride, int32_t *__restrict__ out_len,
+                                               int32_t *__restrict__ n_pdu, uint8_t *__restrict__ bits_out, int bits_stride,
+                                               int strict, const SchedTotals *__restrict__ totals)
+{
+    decode_wave<TWO_TILES, WAVES>(llr, info, slot_frame, groups, n_groups, dec, bitsw, out, out_stride, out_len, n_pdu,
+                                  bits_out, bits_stride, strict, totals);
+}
+
+// k_decode<false, 1> held to 216 registers per lane (the attribute counts in pairs on this target): two such waves
+// leave 80 of a SIMD's 512 registers, which is room for a wave of k_preamble or k_demod of the next batch.
+__global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(108)))
+void k_decode_lean(const float *__restrict__ llr, const gr80211_frame_info *__restrict__ info,
+                   const int32_t *__restrict__ slot_frame, const GroupInfo *__restrict__ groups, int n_groups,
+                   uint32_t *__restrict__ dec, uint32_t *__restrict__ bitsw, uint8_t *__restrict__ out, int out_stride,
+                   int32_t *__restrict__ out_len, int32_t *__restrict__ n_pdu, uint8_t *__restrict__ bits_out,
+                   int bits_stride, int strict, const SchedTotals *__restrict__ totals)
+{
+    decode_wave<false, 1>(llr, info, slot_frame, groups, n_groups, dec, bitsw, out, out_stride, out_len, n_pdu, bits_out,
+                          bits_stride, strict, totals);
 }
 
 // =========================================================================================
@@ -2088,7 +2114,7 @@ void launch_decode(const float *llr, const gr80211_frame_info *info, const int32
                            llr, info, slot_frame, groups, n_groups, dec, bitsw, out, out_stride, out_len, n_pdu, bits_out,
                            bits_stride, strict, totals);
     else
-        hipLaunchKernelGGL((k_decode<false, 1>), dim3(n_groups), dim3(64), 0, s, llr, info, slot_frame, groups, n_groups, dec,
+        hipLaunchKernelGGL(k_decode_lean, dim3(n_groups), dim3(64), 0, s, llr, info, slot_frame, groups, n_groups, dec,
                            bitsw, out, out_stride, out_len, n_pdu, bits_out, bits_stride, strict, totals);
 }
 void launch_decode_split2(const float *llr, const gr80211_frame_info *info, const int32_t *slot_frame, const GroupInfo *groups,

@@ -12,7 +12,7 @@ import os
 import re
 import sys
 
-KERNELS = {"k_decode": "k_decode", "k_demod": "k_demod", "k_preamble": "k_preamble", "k_viterbi_split": "k_viterbi_split",
+KERNELS = {"k_decode": "k_decode(?:_lean)?", "k_demod": "k_demod", "k_preamble": "k_preamble", "k_viterbi_split": "k_viterbi_split",
            "k_traceback": "k_traceback", "k_det_ac": "k_det_ac"}
 
 
