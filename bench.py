@@ -324,9 +324,13 @@ def main():
     ap.add_argument("--detect", action="store_true", help="also time frame detection over the raw capture")
     ap.add_argument("--host-buffers", action="store_true", help="also time one step with PCIe transfers included")
     ap.add_argument("--profile-steps", type=int, default=3, help="extra untimed steps with per-kernel HIP events")
-    ap.add_argument("--pipeline", type=int, default=3,
+    ap.add_argument("--pipeline", type=int, default=0,
                     help="contexts the timed steps rotate over (one host thread, nothing waited for between steps); "
-                         "1 = one batch at a time")
+                         "1 = one batch at a time; 0 = three at N = 1, two at N > 1 (a process has three hardware "
+                         "queues beside the default stream's: the collective's stream takes one)")
+    ap.add_argument("--side-copy", action="store_true",
+                    help="N = 1 only: after every step copy the PDU slots on one more stream, ordered as the gather of "
+                         "an N > 1 run is (stands in for the collective's stream: what one more stream costs)")
     ap.add_argument("--in-flight", type=int, default=2,
                     help="also time the same steps with this many batches in flight (one context, stream and host "
                          "thread each; N = 1 only; 1 = skip)")
@@ -376,7 +380,7 @@ def main():
     # sized the buffers), so the tail of one batch's decoder -- SIMDs that held one trellis fall idle before those that
     # held two -- runs beside the next batch's preamble, demodulator and first decoder waves.  Every step is a whole
     # pass over the whole batch; the steps differ only in where their results land.
-    pipe = max(1, args.pipeline)
+    pipe = args.pipeline if args.pipeline > 0 else (3 if world == 1 else 2)
     depth = max(pipe, 2 if world > 1 else 1)
     ctxs = [ctx] + [pkg.RxContext(local) for _ in range(pipe - 1)]
     outs = [(torch.zeros((n, out_stride), dtype=torch.uint8, device=dev),
@@ -387,6 +391,9 @@ def main():
     gatherer = shard.PduGather(n, out_stride, dev, dst=0, depth=depth) if world > 1 else None
     counter = [0]
     no_wait = [False]
+    side = torch.cuda.Stream() if (args.side_copy and world == 1) else None
+    side_dst = [torch.empty_like(o[0]) for o in outs] if side is not None else None
+    side_done = [None] * depth
 
     # Kernels and collective share a stream explicitly: every step runs under the torch view of its context's own
     # stream (streams a context creates get hardware queues of their own; two from torch's pool were seen to share
@@ -404,7 +411,14 @@ def main():
             assert c._stream().value == c.lib.gr80211_get_stream(c.h), "the library must be handed the context's stream"
             if gatherer is not None:
                 gatherer.wait(slot)  # the batch that used these tensors `depth` steps ago has left
+            if side is not None and side_done[slot] is not None:
+                torch.cuda.current_stream().wait_event(side_done[slot])
             c.rx_batch_into(arena, arena1, desc, n, o, ol, npd, no_wait=no_wait[0])
+            if side is not None:
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    side_dst[slot].copy_(o, non_blocking=True)
+                    side_done[slot] = side.record_event()
             if gatherer is not None:
                 # the one exchange step of the path: decoded MPDUs travel to rank 0 (RCCL gather over xGMI)
                 gatherer.start(slot, o, ol)
