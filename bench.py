@@ -6,9 +6,9 @@
 One rank per GPU (torch.distributed / RCCL when N > 1; RANK, LOCAL_RANK, WORLD_SIZE, MASTER_* from the
 environment).  A step = one pass of the whole RX path (signal -> demod -> decode) over the rank's
 batch of frames, IQ already resident in HBM; for N > 1 the step ends with the gather of the decoded
-MPDUs on rank 0.  The timed steps rotate over three contexts per rank (--pipeline), queued by one host
-thread without a wait between them, so that one batch's decoder tail runs beside the next batch's front
-end; `one_batch_at_a_time` in the output is the same steps on one context.  Rank 0 prints one JSON line.
+MPDUs on rank 0.  The timed steps rotate over four contexts per rank (--pipeline), queued by one host
+thread without a wait between them, so that one batch's decoder tail runs beside the next batches' front
+ends; `one_batch_at_a_time` in the output is the same steps on one context.  Rank 0 prints one JSON line.
 
 Workload (default): BASELINE.json configs[2], the configuration the target is quoted on -- VHT MCS8
 (256-QAM r=3/4) SISO 20 MHz, 1500-byte A-MPDU (1496-byte MPDU), AWGN SNR 30 dB, 100 000 frames per GPU.
@@ -20,7 +20,15 @@ import os
 import sys
 import time
 
-import numpy as np
+# Streams that share a hardware queue run one after the other, and a process gets four queues unless it asks for
+# more: four contexts' streams, the collective's and the default stream want one each.  Read by the HIP runtime when
+# it starts, hence set before torch is imported.  GR80211_BENCH_HW_QUEUES=<n> asks for another number, 0 leaves
+# the environment as it is.
+_q = int(os.environ.get("GR80211_BENCH_HW_QUEUES", "8") or 0)
+if _q > 0:
+    os.environ["GPU_MAX_HW_QUEUES"] = str(min(_q, 32))
+
+import numpy as np  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -326,8 +334,9 @@ def main():
     ap.add_argument("--profile-steps", type=int, default=3, help="extra untimed steps with per-kernel HIP events")
     ap.add_argument("--pipeline", type=int, default=0,
                     help="contexts the timed steps rotate over (one host thread, nothing waited for between steps); "
-                         "1 = one batch at a time; 0 = three at N = 1, two at N > 1 (a process has three hardware "
-                         "queues beside the default stream's: the collective's stream takes one)")
+                         "1 = one batch at a time; 0 = four, or two when the process has only the four hardware "
+                         "queues of the runtime's default (GPU_MAX_HW_QUEUES) and the collective of an N > 1 run "
+                         "needs one of them")
     ap.add_argument("--side-copy", action="store_true",
                     help="N = 1 only: after every step copy the PDU slots on one more stream, ordered as the gather of "
                          "an N > 1 run is (stands in for the collective's stream: what one more stream costs)")
@@ -380,7 +389,8 @@ def main():
     # sized the buffers), so the tail of one batch's decoder -- SIMDs that held one trellis fall idle before those that
     # held two -- runs beside the next batch's preamble, demodulator and first decoder waves.  Every step is a whole
     # pass over the whole batch; the steps differ only in where their results land.
-    pipe = args.pipeline if args.pipeline > 0 else (3 if world == 1 else 2)
+    queues = int(os.environ.get("GPU_MAX_HW_QUEUES", "4") or 4)
+    pipe = args.pipeline if args.pipeline > 0 else (4 if queues >= 6 else 3 if world == 1 else 2)
     depth = max(pipe, 2 if world > 1 else 1)
     ctxs = [ctx] + [pkg.RxContext(local) for _ in range(pipe - 1)]
     outs = [(torch.zeros((n, out_stride), dtype=torch.uint8, device=dev),
@@ -595,7 +605,7 @@ def main():
                    "parallelism": ("frames sharded per rank, gather of MPDUs to rank 0 over %s" %
                                    ("RCCL" if backend == "nccl" else backend + " (host-staged rehearsal, ranks share GPUs)"))
                    if world > 1 else "single GPU",
-                   "batches_in_flight": pipe},
+                   "batches_in_flight": pipe, "hw_queues": queues},
         "psdu": {"frames": n, "fcs_ok": n_ok, "bit_exact_vs_tx": bitexact, "fcs_ok_but_wrong": wrong},
         "kernel_ms": timing,
     }
