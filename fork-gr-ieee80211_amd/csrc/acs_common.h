@@ -24,6 +24,17 @@ __device__ __forceinline__ float add_tab(float m, float t0, float t1, float t01)
     }
 }
 
+// The larger of two path metrics as one v_max_f32.  fmaxf would first quiet a possible signalling NaN in every operand
+// whose origin the compiler cannot see -- a v_max_f32 of its own for each metric that enters a step unchanged from the
+// loop's previous round, 32 per pair of puncture periods.  No signalling NaN gets here: a metric is a constant, a sum
+// (an add quiets what it is given) or the result of this instruction.
+__device__ __forceinline__ float metric_max(float a, float b)
+{
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 // Puncture patterns (lib/cloud80211phy.cc:1857-1860): P trellis steps consume COLS soft bits.
 template <int CR> struct Rate;
 template <> struct Rate<CR_12> { static constexpr int P = 1, COLS = 2, NPER = 32; };

@@ -1322,7 +1322,7 @@ __device__ __forceinline__ void acs_quad(const float (&m)[64], float (&o)[64], f
 #pragma unroll
     for (int k = 0; k < 4; k++) df[k] = a0[k] - a1[k];
 #pragma unroll
-    for (int k = 0; k < 4; k++) o[N + 8 * k] = fmaxf(a0[k], a1[k]);
+    for (int k = 0; k < 4; k++) o[N + 8 * k] = metric_max(a0[k], a1[k]);
 #pragma unroll
     for (int k = 0; k < 4; k++) dw[k] = __builtin_amdgcn_alignbit(dw[k], __float_as_uint(df[k]), 31);
 }

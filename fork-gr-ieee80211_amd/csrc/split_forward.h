@@ -38,8 +38,8 @@ __device__ __forceinline__ void bfly4(const float (&X)[NX], float *ol, float *oh
     }
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        ol[k] = fmaxf(l0[k], l1[k]);
-        oh[k] = fmaxf(h0[k], h1[k]);
+        ol[k] = metric_max(l0[k], l1[k]);
+        oh[k] = metric_max(h0[k], h1[k]);
     }
     accl = 0;
     acch = 0;
