@@ -13,7 +13,7 @@ OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 cd "$ROOT"
-echo "[profile_round] bench"; timeout -k 10 400 python3 bench.py --steps 5 --warmup 2 "$@" > "$OUT/bench.log" 2>"$OUT/bench.err" || exit 1
+echo "[profile_round] bench"; timeout -k 10 400 python3 bench.py "$@" > "$OUT/bench.log" 2>"$OUT/bench.err" || exit 1
 echo "[profile_round] kernel trace"; timeout -k 10 300 rocprofv3 --kernel-trace --stats -d "$OUT/kt" -o kt -- python3 bench.py --steps 5 --warmup 2 --cpu-frames 0 --profile-steps 0 --in-flight 1 --pipeline 1 "$@" > "$OUT/kt.log" 2>&1 || exit 2
 python3 tools/rocpd_summary.py "$OUT"/kt/kt_results.db > "$OUT/kernel_stats.txt" 2>&1
 rm -rf "$OUT/kt"
