@@ -26,6 +26,8 @@ def run(args, n_samples, label, pin=True):
         print(label, "failed", p.returncode, p.stderr[-500:], flush=True)
         return
     sec = float(tm[0].split("seconds=")[1])
+    if os.environ.get("GR80211_BLOCK_PROFILE"):  # where the block's host thread spent its time
+        print(p.stderr.strip(), flush=True)
     print("%-34s %s  %.3f s  %.1f Msamples/s" % (label, stat[0], sec, n_samples / sec / 1e6), flush=True)
 
 
