@@ -52,6 +52,7 @@ DEMOD_SHAPE = {"vht_mcs8_1500B_snr30": (39, 1, 16224), "vht_mcs4_1500B_snr30": (
                "l_mcs0_1000B_snr30": (335, 1, 16080), "ht_mcs15_2x2_1500B_snr30": (24, 2, 14976)}
 H22 = ((1.0, 0.5j), (0.4, -1.0))  # fixed well-conditioned 2x2 channel of the two-antenna workload
 HBM_PEAK_GBS = 8000.0
+COPY_KERNEL_GBS = 4950.0  # measured: bytes read + bytes written of a float4 copy kernel over 3 GiB
 
 
 def build_corpus(torch, tx, wl, n_frames, n_unique, seed, dev):
@@ -687,7 +688,10 @@ def main():
             km = (ctr or {}).get("k_demod", {})
             tr = (2.0 * km["FETCH_SIZE_KiB"] + km["WRITE_SIZE_KiB"]) * 1024.0 if "FETCH_SIZE_KiB" in km and "WRITE_SIZE_KiB" in km else None
             res["roofline"]["k_demod"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                          "frac": ach / HBM_PEAK_GBS, "algorithmic_bytes_per_frame": b_demod, "traffic": tr}
+                                          "frac": ach / HBM_PEAK_GBS, "algorithmic_bytes_per_frame": b_demod, "traffic": tr,
+                                          "copy_kernel_gbs": COPY_KERNEL_GBS,
+                                          "note": "copy_kernel_gbs: what a plain device-to-device copy kernel sustains "
+                                                  "on this chip (tools/ubench/hbm.hip, profiles/r02_hbm_ubench.txt)"}
     if rank == 0 and world == 1 and args.detect and extra is None:
         # raw capture in: frame detection (presiso -> trigger -> sync) finds the frames, `signal`'s trigger search
         # picks the ones it deals with, then the same RX kernels run; reported beside the headline, which starts
