@@ -84,7 +84,8 @@ struct gr80211_ctx {
     uint32_t mu_pos = 0;  // MU group position written into the descriptors frame detection makes
     bool profiling = false;
     bool split_decode = false;  // GR80211_SPLIT_DECODE=1: forward pass and traceback as two kernels
-    int group_waves = -1;       // GR80211_GROUP_WAVES=1|2|4: wavefronts per decoder group (-1: by batch size)
+    int group_waves = -1;       // GR80211_GROUP_WAVES=1|2|4: wavefronts per decoder group (-1: by batch size); 10: one, in the
+                                // form batches of more than 1024 groups take (k_decode_lean) whatever the size
     hipEvent_t ev[7] = {};
     float ms[6] = {};
 };
@@ -300,6 +301,7 @@ int finish_decode_stages(gr80211_ctx *c, hipStream_t s, int n, bool from_iq, con
             // four waves per group while their quarter-waves fit two to a SIMD, two up to one group per SIMD, one beyond
             // (tools/width_sweep.sh: 500 groups 5.6 / 6.5 / 7.7 ms by four / two / one waves, 625 groups 7.8 / 6.8 / 7.9,
             // 1024 groups 11.4 / 8.0 / 8.9, 1125 groups 13.0 / 11.8 / 10.6)
+            if (gw == 10) gw = 1;  // one wave per group in the form large batches take
             if (gw != 1 && gw != 2 && gw != 4) gw = tot.n_groups <= 512 ? 4 : tot.n_groups <= 1024 ? 2 : 1;
             if (gw == 2 && !c->split_decode) {
                 launch_decode_split2(llr, info, (const int32_t *)c->slot_frame.p, (const GroupInfo *)c->groups.p, tot.n_groups,
@@ -328,7 +330,7 @@ int finish_decode_stages(gr80211_ctx *c, hipStream_t s, int n, bool from_iq, con
                 // one kernel: the timing slot of the forward pass then covers the traceback as well
                 launch_decode(llr, info, (const int32_t *)c->slot_frame.p, (const GroupInfo *)c->groups.p,
                               tot.n_groups, (uint32_t *)c->dec.p, (uint32_t *)c->bitsw.p, d_out, out_stride,
-                              d_out_len, d_n_pdu, d_bits, bits_stride, c->ampdu_strict, dt, s);
+                              d_out_len, d_n_pdu, d_bits, bits_stride, c->ampdu_strict, dt, c->group_waves == 10, s);
                 mark(c, 4, s);
             }
         } else {

@@ -73,7 +73,7 @@ void launch_viterbi_split2(const float *llr, const gr80211_frame_info *info, con
 void launch_decode(const float *llr, const gr80211_frame_info *info, const int32_t *slot_frame,
                    const GroupInfo *groups, int n_groups, uint32_t *dec, uint32_t *bitsw, uint8_t *out, int out_stride,
                    int32_t *out_len, int32_t *n_pdu, uint8_t *bits_out, int bits_stride, int strict,
-                   const SchedTotals *totals, hipStream_t s);
+                   const SchedTotals *totals, bool large_form, hipStream_t s);
 // Groups a decoder kernel may run: the launch's count, cut to what the scheduler reports on the device.
 __device__ __forceinline__ int groups_to_run(int n_groups, const SchedTotals *totals)
 {

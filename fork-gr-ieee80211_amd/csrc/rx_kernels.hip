@@ -2105,13 +2105,13 @@ void launch_traceback(const uint32_t *dec, const gr80211_frame_info *info, const
 void launch_decode(const float *llr, const gr80211_frame_info *info, const int32_t *slot_frame,
                    const GroupInfo *groups, int n_groups, uint32_t *dec, uint32_t *bitsw, uint8_t *out, int out_stride,
                    int32_t *out_len, int32_t *n_pdu, uint8_t *bits_out, int bits_stride, int strict,
-                   const SchedTotals *totals, hipStream_t s)
+                   const SchedTotals *totals, bool large_form, hipStream_t s)
 {
     // A batch of at most one group per SIMD runs fastest with exactly one wave on every SIMD (a lone wave finishes
     // its trellis in three quarters of the time a paired one needs): workgroups of four waves with two LDS tiles each,
     // 130 KB per workgroup, so a CU takes one workgroup and 256 workgroups cover the 256 CUs.  Larger batches run one
     // group per workgroup with one tile (16 KB), two waves per SIMD.
-    if (n_groups <= 1024)
+    if (n_groups <= 1024 && !large_form)
         hipLaunchKernelGGL((k_decode<true, DEC_WAVES>), dim3((n_groups + DEC_WAVES - 1) / DEC_WAVES), dim3(64 * DEC_WAVES), 0, s,
                            llr, info, slot_frame, groups, n_groups, dec, bitsw, out, out_stride, out_len, n_pdu, bits_out,
                            bits_stride, strict, totals);

@@ -435,10 +435,11 @@ void gr80211_host_free(gr80211_ctx *ctx, void *p);
 /*
  * Timing of the last batch call, measured with HIP events on the stream the kernels ran on.
  * ms[0]=preamble, [1]=schedule, [2]=demod, [3]=decode (Viterbi forward pass + traceback + assembly, one kernel),
- * [4]=0, [5]=whole call.  Batches of at most 640 decoder groups (about 41 000 frames of one code rate) run the
+ * [4]=0, [5]=whole call.  Batches of at most 512 decoder groups (about 33 000 frames of one code rate) run the
  * forward pass with four wavefronts per group and the traceback as a second kernel: [3] is then the forward pass
- * and [4] the traceback + assembly (the environment variables GR80211_GROUP_WAVES=1|4 and GR80211_SPLIT_DECODE=1
- * force either form for experiments).
+ * and [4] the traceback + assembly; up to 1024 groups two wavefronts share a group, beyond that one wavefront runs
+ * it (the environment variables GR80211_GROUP_WAVES=1|2|4, or 10 for the one-wavefront form of the largest batches
+ * at any size, and GR80211_SPLIT_DECODE=1 force a form for experiments).
  * Only recorded when profiling is switched on (costs one stream synchronisation per call).
  */
 int gr80211_set_profiling(gr80211_ctx *ctx, int on);

@@ -180,13 +180,14 @@ def test_linearity_property_full_size(pkg, rxctx, oracle):
 
 @pytest.fixture(scope="module")
 def ctx_by_waves(pkg):
-    """Contexts pinned to 1, 2 and 4 wavefronts per decoder group (by default the library chooses by batch size,
-    so the small batches of these tests would all take the four-wave path)."""
+    """Contexts pinned to 1, 2 and 4 wavefronts per decoder group, and to the one-wave form of batches beyond 1024
+    groups (10) (by default the library chooses by batch size, so the small batches of these tests would all take the
+    four-wave path)."""
     import os
     made = {}
     old = os.environ.get("GR80211_GROUP_WAVES")
     try:
-        for w in (1, 2, 4):
+        for w in (1, 2, 4, 10):
             os.environ["GR80211_GROUP_WAVES"] = str(w)
             made[w] = pkg.RxContext(0)
     finally:
@@ -199,7 +200,7 @@ def ctx_by_waves(pkg):
         c.close()
 
 
-@pytest.mark.parametrize("waves", [1, 2, 4])
+@pytest.mark.parametrize("waves", [1, 2, 4, 10])
 def test_each_group_width_against_oracle(pkg, ctx_by_waves, oracle, waves):
     """Ragged lengths, all four code rates, integer LLRs with many ties: every way of spreading a group over
     wavefronts gives the oracle's bits and PDUs."""
