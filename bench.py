@@ -680,6 +680,16 @@ def main():
         vi["mix_floor_cycles"] = MIX_FLOOR_CYCLES
         vi["frac_of_mix_floor"] = MIX_FLOOR_CYCLES / vi["simd_cycles_per_wave_state_update"]
         res["roofline"]["valu_issue"] = vi
+        if pipe > 1 and "clock_ghz_under_load" in vi and all("SQ_INSTS_VALU" in (ctr or {}).get(k, {}) for k in ("k_demod", "k_preamble")):
+            # the timed steps, with the kernels of several batches side by side: what all of a step's kernels issue
+            # against the SIMD cycles one step takes
+            insts = kd["SQ_INSTS_VALU"] + ctr["k_demod"]["SQ_INSTS_VALU"] + ctr["k_preamble"]["SQ_INSTS_VALU"]
+            cyc = 1024.0 * vi["clock_ghz_under_load"] * 1e9 * res["ms_per_step"] * 1e-3
+            res["roofline"]["rotation"] = {"valu_insts_per_step": insts, "simd_cycles_per_inst": cyc / insts,
+                                           "issue_slots_used_frac": 2.0 * insts / cyc,
+                                           "note": "decoder, demodulator and preamble kernels of one step (counters of the "
+                                                   "profiled launches) over the SIMD cycles of ms_per_step at the clock "
+                                                   "measured under the decoder"}
         if extra is None and timing.get("demod", 0.0) > 0:
             # the kernel of the path that HBM does bound: samples in, soft bits out
             nsym, nrx, nllr = DEMOD_SHAPE[args.workload]
