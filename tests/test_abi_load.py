@@ -136,3 +136,33 @@ def test_tx_frame_lengths_match_generator(pkg):
     for bad in ():
         assert lib.gr80211_tx_samples(*bad) == -1, bad
     assert ctypes.sizeof(ctypes.c_char * pkg.rx.TX_DESC_DTYPE.itemsize) == 40
+
+
+def test_large_batch_decoder_leaves_register_room(pkg, tmp_path):
+    """Two waves of the one-wave decoder of large batches must leave a SIMD's register file (512 per lane) room for a
+    72-register wave of the next batch's preamble or demodulator kernel: at most 216 registers.  The limit is a
+    function attribute whose unit the compiler defines (it counts in pairs on this target), so the result is read
+    from the code object the library carries."""
+    import shutil
+    import subprocess
+    tools = "/opt/rocm/lib/llvm/bin"
+    if not (os.path.exists(os.path.join(tools, "llvm-objdump")) and os.path.exists(os.path.join(tools, "llvm-readelf"))):
+        import pytest
+        pytest.skip("no llvm-objdump / llvm-readelf on this machine")
+    so = tmp_path / "lib.so"
+    shutil.copy(pkg.rx.LIB_PATH, so)
+    subprocess.run([os.path.join(tools, "llvm-objdump"), "--offloading", str(so)], check=True, capture_output=True, cwd=tmp_path)
+    found = {}
+    for f in sorted(tmp_path.glob("lib.so.*gfx950*")):
+        notes = subprocess.run([os.path.join(tools, "llvm-readelf"), "--notes", str(f)], capture_output=True, text=True).stdout
+        for m in re.finditer(r"\.name:\s+(\S+)(.*?)\.vgpr_count:\s+(\d+)", notes, flags=re.S):
+            if "\n    .name:" in m.group(2):
+                continue  # ran into the next kernel's record
+            found[m.group(1)] = int(m.group(3))
+    lean = [v for k, v in found.items() if "k_decode_lean" in k]
+    demod = [v for k, v in found.items() if "k_demodILi1E" in k]
+    pre = [v for k, v in found.items() if "k_preamble" in k]
+    assert len(lean) == 1 and len(demod) == 1 and len(pre) == 1, sorted(found)
+    gran = 8  # registers are handed out in blocks of eight
+    up = lambda v: (v + gran - 1) // gran * gran
+    assert 2 * up(lean[0]) + up(demod[0]) <= 512 and 2 * up(lean[0]) + up(pre[0]) <= 512, (lean, demod, pre)
