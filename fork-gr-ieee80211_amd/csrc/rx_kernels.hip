@@ -1146,9 +1146,12 @@ __device__ __forceinline__ c32 derot(int k, float rad)
 
 // One workgroup per frame; the instantiation for the frame's number of spatial streams does the work, the other
 // one leaves at once (two kernels keep the one-stream path's registers, and with them its occupancy, free of the
-// 2x2 channel matrices).
+// 2x2 channel matrices).  At most 96 registers per lane (the attribute counts in pairs on this target): five waves
+// of the two-stream form per SIMD instead of four (103 registers without it; four values spilled), which this
+// latency-bound kernel turns into 1.29 -> 1.10 ms at 50 000 two-stream frames; the one-stream form needs 67 anyway.
 template <int NSS>
-__global__ __launch_bounds__(64 * DEMOD_WAVES) void k_demod(const c32 *__restrict__ iq0, const c32 *__restrict__ iq1,
+__global__ __launch_bounds__(64 * DEMOD_WAVES) __attribute__((amdgpu_num_vgpr(48)))
+void k_demod(const c32 *__restrict__ iq0, const c32 *__restrict__ iq1,
                                                             uint64_t arena_len,
                                                             const gr80211_frame_desc *__restrict__ descs, int n,
                                                             const gr80211_frame_info *__restrict__ info,
