@@ -323,7 +323,7 @@ MIX_FLOOR_CYCLES = 14.6
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames", type=int, default=0, help="frames per GPU (0 = the workload's configured size)")
     ap.add_argument("--workload", default="vht_mcs8_1500B_snr30", choices=sorted(WORKLOADS) + [MIXED])
