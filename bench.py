@@ -6,7 +6,7 @@
 One rank per GPU (torch.distributed / RCCL when N > 1; RANK, LOCAL_RANK, WORLD_SIZE, MASTER_* from the
 environment).  A step = one pass of the whole RX path (signal -> demod -> decode) over the rank's
 batch of frames, IQ already resident in HBM; for N > 1 the step ends with the gather of the decoded
-MPDUs on rank 0.  The timed steps rotate over four contexts per rank (--pipeline), queued by one host
+MPDUs on rank 0.  The timed steps rotate over six contexts per rank (--pipeline), queued by one host
 thread without a wait between them, so that one batch's decoder tail runs beside the next batches' front
 ends; `one_batch_at_a_time` in the output is the same steps on one context.  Rank 0 prints one JSON line.
 
@@ -21,7 +21,7 @@ import sys
 import time
 
 # Streams that share a hardware queue run one after the other, and a process gets four queues unless it asks for
-# more: four contexts' streams, the collective's and the default stream want one each.  Read by the HIP runtime when
+# more: six contexts' streams, the collective's and the default stream want one each.  Read by the HIP runtime when
 # it starts, hence set before torch is imported.  GR80211_BENCH_HW_QUEUES=<n> asks for another number, 0 leaves
 # the environment as it is.
 _q = int(os.environ.get("GR80211_BENCH_HW_QUEUES", "8") or 0)
@@ -335,7 +335,7 @@ def main():
     ap.add_argument("--profile-steps", type=int, default=3, help="extra untimed steps with per-kernel HIP events")
     ap.add_argument("--pipeline", type=int, default=0,
                     help="contexts the timed steps rotate over (one host thread, nothing waited for between steps); "
-                         "1 = one batch at a time; 0 = four, or two when the process has only the four hardware "
+                         "1 = one batch at a time; 0 = six, or two when the process has only the four hardware "
                          "queues of the runtime's default (GPU_MAX_HW_QUEUES) and the collective of an N > 1 run "
                          "needs one of them")
     ap.add_argument("--side-copy", action="store_true",
@@ -391,7 +391,7 @@ def main():
     # held two -- runs beside the next batch's preamble, demodulator and first decoder waves.  Every step is a whole
     # pass over the whole batch; the steps differ only in where their results land.
     queues = int(os.environ.get("GPU_MAX_HW_QUEUES", "4") or 4)
-    pipe = args.pipeline if args.pipeline > 0 else (4 if queues >= 6 else 3 if world == 1 else 2)
+    pipe = args.pipeline if args.pipeline > 0 else (6 if queues >= 8 else 3 if world == 1 else 2)
     depth = max(pipe, 2 if world > 1 else 1)
     ctxs = [ctx] + [pkg.RxContext(local) for _ in range(pipe - 1)]
     outs = [(torch.zeros((n, out_stride), dtype=torch.uint8, device=dev),
