@@ -12,6 +12,12 @@ ends; `one_batch_at_a_time` in the output is the same steps on one context.  Ran
 
 Workload (default): BASELINE.json configs[2], the configuration the target is quoted on -- VHT MCS8
 (256-QAM r=3/4) SISO 20 MHz, 1500-byte A-MPDU (1496-byte MPDU), AWGN SNR 30 dB, 100 000 frames per GPU.
+
+`python bench.py --gpus N` without a launcher starts itself under torch.distributed.run (one rank per GPU) before
+anything touches a GPU and relays rank 0's line.  At N = 8 the line also carries `capture_corpus`: BASELINE.json
+configs[4], the reference's own IQ files and the frames of its Python generator replicated to 125 000 frames per GPU,
+with the length-compacted gather (`--capture-corpus 1` adds it at any N; `--workload capture_corpus_replicated` makes it
+the workload of the headline fields).
 """
 import argparse
 import importlib
@@ -43,7 +49,7 @@ WORKLOADS = {
 }
 # frames per GPU the configuration list quotes for each workload, and trellis steps per frame
 DEFAULT_FRAMES = {"vht_mcs8_1500B_snr30": 100000, "vht_mcs4_1500B_snr30": 10000, "l_mcs0_1000B_snr30": 10000,
-                  "ht_mcs15_2x2_1500B_snr30": 50000, "mixed_l_ht_vht_snr30": 125000}
+                  "ht_mcs15_2x2_1500B_snr30": 50000, "mixed_l_ht_vht_snr30": 125000, "capture_corpus_replicated": 125000}
 TRELLIS_STEPS = {"vht_mcs8_1500B_snr30": 12168, "vht_mcs4_1500B_snr30": 12168, "l_mcs0_1000B_snr30": 8022,
                  "ht_mcs15_2x2_1500B_snr30": 12022}
 # k_demod's own algorithmic bytes per frame: the data symbols' samples in (80 per symbol and antenna, 8 B each) and the
@@ -274,11 +280,11 @@ def cpu_baseline(arena_host, arena1_host, sync, navail, n_sample, gpu_blobs, bud
     t0 = time.perf_counter()
     d1 = run(0, n1, t0 + budget_s)
     dt1 = time.perf_counter() - t0
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        cores = os.cpu_count() or 1
-    cores = max(1, min(cores, int(os.environ.get("OMP_NUM_THREADS", "16")), 64))
+    # one thread per physical core this process may run on (its affinity mask, /proc/cpuinfo's topology); the box's
+    # share of the machine (OMP_NUM_THREADS, set by the harness) caps it where the mask shows the whole machine
+    model, phys, logical = host_cpu()
+    share = int(os.environ.get("OMP_NUM_THREADS", "0") or 0)
+    cores = max(1, min(phys, share) if share > 0 else phys)
     per = (n_sample + cores - 1) // cores
     t0 = time.perf_counter()
     with ThreadPoolExecutor(cores) as ex:
@@ -289,7 +295,8 @@ def cpu_baseline(arena_host, arena1_host, sync, navail, n_sample, gpu_blobs, bud
     samples = sum(p[1] for p in parts)
     # `frames`, `fcs_ok` and `gpu_mismatches` all describe the threaded leg, the one `value` is measured on; the
     # single-thread leg (a subset of the same frames, run first) has its own three figures
-    return dict(value=samples / dtn / 1e6, unit="Msamples/s", cores=cores, kind="port",
+    return dict(value=samples / dtn / 1e6, unit="Msamples/s", cores=cores, kind="port", cpu_model=model,
+                physical_cores_visible=phys, logical_cpus_visible=logical, cpu_share_of_the_box=share or None,
                 sample="first %d frames of the benchmark corpus (%d samples) sharded over %d threads of the CPU "
                        "oracle, %.1f s; one thread alone: %d frames in %.1f s" % (n_done, samples, cores, dtn, d1[0], dt1),
                 frames=n_done, fcs_ok=sum(p[3] for p in parts), gpu_mismatches=sum(p[2] for p in parts),
@@ -320,13 +327,238 @@ FLOP_PER_STATE_UPDATE = 3.0       # two float adds and one compare-select per tr
 MIX_FLOOR_CYCLES = 14.6
 
 
+def launch_ranks(n_ranks):
+    """Starts this script again under torch.distributed.run, one rank per GPU, as a child process; relays what the
+    ranks print and leaves with the launcher's exit code.  Called before torch is imported: this process never
+    touches a GPU."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # RCCL shares memory between ranks by dmabuf handles
+    env.setdefault("OMP_NUM_THREADS", "16")
+    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, bufsize=1)
+    for line in child.stdout:
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    sys.exit(child.wait())
+
+
+def host_cpu():
+    """(CPU model string, physical cores this process may run on, logical CPUs it may run on) from /proc/cpuinfo and
+    the process's affinity mask: a physical core is a distinct (physical id, core id) pair among the allowed CPUs."""
+    try:
+        allowed = set(os.sched_getaffinity(0))
+    except AttributeError:
+        allowed = set(range(os.cpu_count() or 1))
+    model, cores, cur = "unknown", set(), {}
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f.read().split("\n") + [""]:
+                if not line.strip():
+                    if cur and int(cur.get("processor", -1)) in allowed:
+                        cores.add((cur.get("physical id", "0"), cur.get("core id", cur.get("processor"))))
+                    cur = {}
+                    continue
+                k, _, v = line.partition(":")
+                cur[k.strip()] = v.strip()
+                if k.strip() == "model name":
+                    model = v.strip()
+    except OSError:
+        pass
+    return model, max(1, len(cores)) if cores else len(allowed), len(allowed)
+
+
+CAPTURE = "capture_corpus_replicated"
+
+
+def build_corpus_capture(torch, ctx, n_frames, dev):
+    """BASELINE.json configs[4]: the reference's own IQ files (one legacy frame on one antenna, one HT MCS8 frame on
+    two) and the frames made by its Python generator (tests/golden/frame_*.npz: legacy, HT and VHT, one and two
+    streams), replicated round-robin to n_frames.  One- and two-antenna sources form the two parts of a step (the
+    `demod` and the `demod2` chain).  Expected PDUs come from the MPDUs the fixtures carry, not from the oracle.
+    Returns a dict: parts [(arena0, arena1, desc, n, row_lo)], exp [u, blob_len], idx [n], totals."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import util as TU
+    h22 = np.array(H22, dtype=np.complex128)
+    srcs = []  # (antenna arrays, sync index, rad, format, mcs, mpdu)
+    for f in TU.golden_frames():
+        if f["nss"] == 1:
+            srcs.append(([f["iq"][0].astype(np.complex64)], f["sync_idx"], f["rad"], f["fmt"], f["mcs"], f["mpdu"]))
+        else:
+            rx = (h22 @ f["iq"]).astype(np.complex64)
+            srcs.append(([rx[0], rx[1]], f["sync_idx"], f["rad"], f["fmt"], f["mcs"], f["mpdu"]))
+    ref_mpdu = TU.ref_fixture_mpdu()
+    for (name, ants, sidx), (fmt, mcs) in zip(TU.ref_fixtures(), ((0, 0), (1, 8))):
+        srcs.append((ants, sidx, 0.0, fmt, mcs, ref_mpdu))
+    u = len(srcs)
+    blob_len = max(len(s[5]) for s in srcs) + 4
+    exp = np.zeros((u, blob_len), np.uint8)
+    exp_len = np.zeros(u, np.int32)
+    for k, s_ in enumerate(srcs):
+        m = s_[5]
+        b = bytes([s_[3], len(m) % 256, len(m) // 256]) + m + bytes([s_[4]])
+        exp[k, :len(b)] = np.frombuffer(b, np.uint8)
+        exp_len[k] = len(b)
+    kind_of = np.arange(n_frames) % u
+    parts, row_lo, samples, psdu_bytes, on_air = [], 0, 0.0, 0.0, np.zeros(u)
+    order = []
+    for nant in (1, 2):
+        ks = [k for k in range(u) if len(srcs[k][0]) == nant]
+        if not ks:
+            continue
+        frames = np.nonzero(np.isin(kind_of, ks))[0]          # this part's frames, in corpus order
+        blk = [np.concatenate([srcs[k][0][a] for k in ks]) for a in range(nant)]
+        blk_len = len(blk[0])
+        offs, navail_u, pos = {}, {}, 0
+        for k in ks:
+            offs[k] = pos + srcs[k][1]
+            navail_u[k] = len(srcs[k][0][0]) - srcs[k][1]
+            pos += len(srcs[k][0][0])
+        reps = (len(frames) + len(ks) - 1) // len(ks) + 1
+        arenas = [torch.cat([torch.from_numpy(b).to(dev).repeat(reps), torch.zeros(64, dtype=torch.complex64, device=dev)])
+                  for b in blk]
+        # the j-th frame of kind k sits in replica j of the block
+        rep_of = np.zeros(len(frames), np.int64)
+        for k in ks:
+            sel = kind_of[frames] == k
+            rep_of[sel] = np.arange(int(sel.sum()))
+        kk = kind_of[frames]
+        sync = rep_of.astype(np.uint64) * np.uint64(blk_len) + np.array([offs[k] for k in kk], dtype=np.uint64)
+        navail = np.array([navail_u[k] for k in kk], dtype=np.uint32)
+        rads = np.array([srcs[k][2] for k in kk], dtype=np.float32)
+        desc = torch.from_numpy(ctx.make_desc(sync, navail, rad=rads).view(np.uint8).reshape(-1)).to(dev)
+        # on-air samples of every source frame: preamble (400) + what the L-SIG announces
+        first = [int(np.nonzero(kk == k)[0][0]) for k in ks]
+        info = ctx.signal_batch(arenas[0], arenas[1] if nant == 2 else None,
+                                ctx.make_desc(sync[first], navail[first], rad=rads[first]), len(first))
+        for k, fi in zip(ks, info):
+            on_air[k] = 400 + int(fi["nsamp"])
+        parts.append((arenas[0], arenas[1] if nant == 2 else None, desc, len(frames), row_lo, nant))
+        order.append(frames)
+        row_lo += len(frames)
+    order = np.concatenate(order)                            # output row -> corpus frame
+    idx = torch.from_numpy(kind_of[order]).to(dev)
+    nrx = np.array([len(s_[0]) for s_ in srcs])
+    per_kind_bytes = 8.0 * nrx * on_air + np.array([len(s_[5]) for s_ in srcs]) + 64
+    return {"parts": parts, "n": n_frames, "exp": torch.from_numpy(exp).to(dev), "exp_len": torch.from_numpy(exp_len).to(dev),
+            "idx": idx, "blob_len": blob_len, "total_samples": float(on_air[kind_of].sum()),
+            "b_alg": float(per_kind_bytes[kind_of].sum()) / n_frames, "sources": u,
+            "source_kinds": [[int(s_[3]), int(s_[4]), len(s_[0]), len(s_[5])] for s_ in srcs]}
+
+
+class Rotation:
+    """The timed steps of one corpus: contexts, their streams, rotating output tensors and the MPDU gather."""
+
+    def __init__(self, torch, dist, pkg, shard, local, dev, parts, n, out_stride, pipe, collective, compact, first_ctx,
+                 side_copy=False):
+        self.torch, self.dist, self.parts, self.n, self.pipe = torch, dist, parts, n, pipe
+        self.depth = max(pipe, 2 if collective else 1)
+        self.ctxs = [first_ctx] + [pkg.RxContext(local) for _ in range(pipe - 1)]
+        self.outs = [(torch.zeros((n, out_stride), dtype=torch.uint8, device=dev),
+                      torch.zeros(n, dtype=torch.int32, device=dev),
+                      torch.zeros(n, dtype=torch.int32, device=dev)) for _ in range(self.depth)]
+        # Kernels and collective share a stream explicitly: every step runs under the torch view of its context's own
+        # stream (streams a context creates get hardware queues of their own; two from torch's pool were seen to share
+        # one), the library is handed that stream, the gather is ordered behind whatever the stream holds when it is
+        # started, and wait() makes the same stream wait for the collective before a slot's tensors are reused.
+        self.streams = [c.own_stream() for c in self.ctxs]
+        self.gatherer = None
+        self.compact = compact
+        if collective:
+            if compact:
+                # the packing kernels go to the stream of the context whose batch they follow
+                self.gatherer = shard.PduGatherCompact(
+                    n, out_stride, dev, lambda o, ol, pk, tot: self.ctxs[self._slot % pipe].pack_pdus(o, ol, pk, tot),
+                    dst=0, depth=self.depth)
+            else:
+                self.gatherer = shard.PduGather(n, out_stride, dev, dst=0, depth=self.depth)
+        self.counter, self.no_wait, self._slot = 0, False, 0
+        self.gathered = None
+        self.side = torch.cuda.Stream() if side_copy else None
+        self.side_dst = [torch.empty_like(o[0]) for o in self.outs] if side_copy else None
+        self.side_done = [None] * self.depth
+
+    def step(self, gather=True):
+        torch = self.torch
+        slot = self.counter % self.depth
+        self.counter += 1
+        self._slot = slot
+        o, ol, npd = self.outs[slot]
+        c = self.ctxs[slot % self.pipe]
+        g = self.gatherer if gather else None
+        with torch.cuda.stream(self.streams[slot % self.pipe]):
+            assert c._stream().value == c.lib.gr80211_get_stream(c.h), "the library must be handed the context's stream"
+            if g is not None:
+                r = g.wait(slot)  # the batch that used these tensors `depth` steps ago has left
+                if r[0] is not None:
+                    self.gathered = r
+            if self.side is not None and self.side_done[slot] is not None:
+                torch.cuda.current_stream().wait_event(self.side_done[slot])
+            for a0, a1, desc, npart, lo, _ in self.parts:
+                c.rx_batch_into(a0, a1, desc, npart, o[lo:lo + npart], ol[lo:lo + npart], npd[lo:lo + npart], no_wait=self.no_wait)
+            if self.side is not None:
+                self.side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(self.side):
+                    self.side_dst[slot].copy_(o, non_blocking=True)
+                    self.side_done[slot] = self.side.record_event()
+            if g is not None:
+                # the one exchange step of the path: decoded MPDUs travel to rank 0
+                g.start(slot, o, ol)
+
+    def fence(self, barrier):
+        torch = self.torch
+        if self.gatherer is not None:
+            for slot in range(self.depth):
+                self._slot = slot
+                with torch.cuda.stream(self.streams[slot % self.pipe]):
+                    r = self.gatherer.wait(slot)
+                if r[0] is not None:
+                    self.gathered = r
+        if barrier:
+            self.dist.barrier()
+        torch.cuda.synchronize()
+
+    def timed(self, steps, warmup, barrier, gather=True):
+        """warm-up (every context's work buffers reach their size), fence, `steps` steps, fence: seconds."""
+        for _ in range(max(warmup, self.pipe)):
+            self.step(gather)
+        self.fence(barrier)
+        self.no_wait = True
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.step(gather)
+        self.fence(barrier)
+        dt = time.perf_counter() - t0
+        refused = [c.last_batch_refused() for c in self.ctxs]
+        if any(refused):
+            raise RuntimeError("a batch queued without the wait found too little room: %r" % (refused,))
+        return dt
+
+    def close(self):
+        for c in self.ctxs[1:]:  # the first context is the caller's
+            c.close()
+
+
+def check_rows(torch, rows, lens, exp, idx):
+    """(FCS passes, of them bit-exact against the expected blob, of them wrong) of PDU slots against exp[idx]."""
+    got = lens > 0
+    m = (rows[:, :exp.shape[1]] == exp[idx]).all(dim=1)
+    return int(got.sum().item()), int((got & m).sum().item()), int((got & ~m).sum().item())
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames", type=int, default=0, help="frames per GPU (0 = the workload's configured size)")
-    ap.add_argument("--workload", default="vht_mcs8_1500B_snr30", choices=sorted(WORKLOADS) + [MIXED])
+    ap.add_argument("--workload", default="vht_mcs8_1500B_snr30", choices=sorted(WORKLOADS) + [MIXED, CAPTURE])
     ap.add_argument("--unique", type=int, default=0,
                     help="distinct payloads in the corpus; 0 = every frame its own, frames made by the GPU transmitter")
     ap.add_argument("--cpu-frames", type=int, default=48000, help="frames timed on the CPU oracle (0 = skip)")
@@ -344,7 +576,19 @@ def main():
     ap.add_argument("--in-flight", type=int, default=2,
                     help="also time the same steps with this many batches in flight (one context, stream and host "
                          "thread each; N = 1 only; 1 = skip)")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="N = 1: run the exchange step all the same (process group of one rank, the gather of the MPDUs on "
+                         "device tensors, its stream ordering and the check of what arrived): the N > 1 code path on one GPU")
+    ap.add_argument("--gather", default="auto", choices=["auto", "fixed", "compact"],
+                    help="exchange of the MPDUs: fixed-stride slots, or blobs packed to their lengths (lengths first, then "
+                         "the bytes); auto = compact for corpora of mixed lengths, fixed for uniform ones")
+    ap.add_argument("--capture-corpus", type=int, default=-1,
+                    help="also time BASELINE.json configs[4] (the reference's IQ files and generator frames replicated, "
+                         "125 000 frames per GPU) and report it as `capture_corpus`: 1 = yes, 0 = no, -1 = only at 8 GPUs")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(args.gpus)  # does not return
 
     import torch
     import torch.distributed as dist
@@ -353,36 +597,55 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (WORLD_SIZE=%d)" % (args.gpus, world))
-    # GR80211_BENCH_BACKEND=gloo rehearses the N > 1 path where RCCL cannot run (several ranks on one GPU):
-    # ranks then share devices round-robin and every collective gets host tensors
-    backend = os.environ.get("GR80211_BENCH_BACKEND", "nccl")
+        sys.exit("bench.py --gpus %d was started with WORLD_SIZE=%d" % (args.gpus, world))
+    # RCCL needs a GPU per rank.  Where there are fewer (a rehearsal of the N > 1 path on one GPU), or with
+    # GR80211_BENCH_BACKEND=gloo, the ranks share devices round-robin and every collective gets host tensors.
+    backend = os.environ.get("GR80211_BENCH_BACKEND") or ("nccl" if torch.cuda.device_count() >= world else "gloo")
     local = local % max(1, torch.cuda.device_count()) if backend == "gloo" else local
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    collective = world > 1 or args.force_collective
+    if collective:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+    cdev = dev if backend == "nccl" else "cpu"
+
+    def max_over_ranks(x):
+        if not collective:
+            return x
+        tt = torch.tensor([x], dtype=torch.float64, device=cdev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return float(tt.item())
 
     pkg = importlib.import_module("fork-gr-ieee80211_amd")
+    shard = importlib.import_module("fork-gr-ieee80211_amd.shard")
     tx = pkg.txgen
     ctx = pkg.RxContext(local)
     n = args.frames if args.frames > 0 else DEFAULT_FRAMES[args.workload]
     tx_info = None
     extra = None
-    if args.workload == MIXED:
-        arenas, sync, navail, exp, idx, L, tx_info, extra = build_corpus_mixed(torch, ctx, tx, n, rank, dev)
-    elif args.unique > 0:
-        arenas, sync, navail, exp, idx, L = build_corpus(torch, tx, args.workload, n, args.unique, rank, dev)
+    cap = None
+    sync = navail = None
+    if args.workload == CAPTURE:
+        cap = build_corpus_capture(torch, ctx, n, dev)
+        parts, exp, idx, L = cap["parts"], cap["exp"], cap["idx"], cap["total_samples"] / n
+        extra = {"total_samples": cap["total_samples"], "b_alg": cap["b_alg"], "total_steps": None}
+        arena, arena1 = parts[0][0], parts[0][1]
     else:
-        arenas, sync, navail, exp, idx, L, tx_info = build_corpus_gpu(torch, ctx, tx, args.workload, n, rank, dev)
-    arena, arena1 = arenas[0], (arenas[1] if len(arenas) > 1 else None)
+        if args.workload == MIXED:
+            arenas, sync, navail, exp, idx, L, tx_info, extra = build_corpus_mixed(torch, ctx, tx, n, rank, dev)
+        elif args.unique > 0:
+            arenas, sync, navail, exp, idx, L = build_corpus(torch, tx, args.workload, n, args.unique, rank, dev)
+        else:
+            arenas, sync, navail, exp, idx, L, tx_info = build_corpus_gpu(torch, ctx, tx, args.workload, n, rank, dev)
+        arena, arena1 = arenas[0], (arenas[1] if len(arenas) > 1 else None)
+        desc = torch.from_numpy(ctx.make_desc(sync, navail).view(np.uint8).reshape(-1)).to(dev)
+        parts = [(arena, arena1, desc, n, 0, 2 if arena1 is not None else 1)]
     fmt, mcs, nss, nbytes, snr_db, b_alg = WORKLOADS[args.workload] if extra is None else (-1, -1, 1, 0, 30.0, extra["b_alg"])
-    desc = torch.from_numpy(ctx.make_desc(sync, navail).view(np.uint8).reshape(-1)).to(dev)
     blob_len = exp.shape[1]
     out_stride = ((blob_len + 4 + 63) // 64) * 64
     # The timed steps rotate over `pipe` contexts, each with its own stream, work buffers and output tensors: step k is
@@ -391,116 +654,52 @@ def main():
     # held two -- runs beside the next batch's preamble, demodulator and first decoder waves.  Every step is a whole
     # pass over the whole batch; the steps differ only in where their results land.
     queues = int(os.environ.get("GPU_MAX_HW_QUEUES", "4") or 4)
-    pipe = args.pipeline if args.pipeline > 0 else (6 if queues >= 8 else 3 if world == 1 else 2)
-    depth = max(pipe, 2 if world > 1 else 1)
-    ctxs = [ctx] + [pkg.RxContext(local) for _ in range(pipe - 1)]
-    outs = [(torch.zeros((n, out_stride), dtype=torch.uint8, device=dev),
-             torch.zeros(n, dtype=torch.int32, device=dev),
-             torch.zeros(n, dtype=torch.int32, device=dev)) for _ in range(depth)]
-    out, out_len, n_pdu = outs[0]
-    shard = importlib.import_module("fork-gr-ieee80211_amd.shard")
-    gatherer = shard.PduGather(n, out_stride, dev, dst=0, depth=depth) if world > 1 else None
-    counter = [0]
-    no_wait = [False]
-    side = torch.cuda.Stream() if (args.side_copy and world == 1) else None
-    side_dst = [torch.empty_like(o[0]) for o in outs] if side is not None else None
-    side_done = [None] * depth
+    pipe = args.pipeline if args.pipeline > 0 else (6 if queues >= 8 else 3 if not collective else 2)
+    compact = args.gather == "compact" or (args.gather == "auto" and args.workload in (MIXED, CAPTURE))
+    rot = Rotation(torch, dist, pkg, shard, local, dev, parts, n, out_stride, pipe, collective, compact, ctx,
+                   side_copy=args.side_copy and not collective)
+    out, out_len, n_pdu = rot.outs[0]
+    dt = max_over_ranks(rot.timed(args.steps, args.warmup, collective))
 
-    # Kernels and collective share a stream explicitly: every step runs under the torch view of its context's own
-    # stream (streams a context creates get hardware queues of their own; two from torch's pool were seen to share
-    # one), the library is handed that stream, RCCL's gather is ordered behind whatever the stream holds when it is
-    # started, and wait() makes the same stream wait for the collective before a slot's tensors are reused.
-    streams = [c.own_stream() for c in ctxs]
-    gathered = [None]
-
-    def step():
-        slot = counter[0] % depth
-        counter[0] += 1
-        o, ol, npd = outs[slot]
-        c = ctxs[slot % pipe]
-        with torch.cuda.stream(streams[slot % pipe]):
-            assert c._stream().value == c.lib.gr80211_get_stream(c.h), "the library must be handed the context's stream"
-            if gatherer is not None:
-                gatherer.wait(slot)  # the batch that used these tensors `depth` steps ago has left
-            if side is not None and side_done[slot] is not None:
-                torch.cuda.current_stream().wait_event(side_done[slot])
-            c.rx_batch_into(arena, arena1, desc, n, o, ol, npd, no_wait=no_wait[0])
-            if side is not None:
-                side.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(side):
-                    side_dst[slot].copy_(o, non_blocking=True)
-                    side_done[slot] = side.record_event()
-            if gatherer is not None:
-                # the one exchange step of the path: decoded MPDUs travel to rank 0 (RCCL gather over xGMI)
-                gatherer.start(slot, o, ol)
-
-    def fence():
-        if gatherer is not None:
-            with torch.cuda.stream(streams[0]):
-                last = gatherer.finish()
-            if last[0] is not None:
-                gathered[0] = last
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(max(args.warmup, pipe)):  # every context's work buffers reach their size
-        step()
-    fence()
-    no_wait[0] = True
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    dt = time.perf_counter() - t0
-    refused = [c.last_batch_refused() for c in ctxs]
-    if any(refused):
-        raise RuntimeError("a batch queued without the wait found too little room: %r" % (refused,))
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-
-    # ---- N > 1: the same steps without the exchange, to show what the gather costs (not the headline)
+    # ---- with the exchange: the same steps without it, to show what the gather costs (not the headline)
     value_local = None
-    if world > 1:
-        saved, gatherer = gatherer, None
-        fence()
+    if collective:
+        rot.fence(True)
         t1 = time.perf_counter()
         for _ in range(args.steps):
-            step()
-        fence()
-        dl = time.perf_counter() - t1
-        tt = torch.tensor([dl], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        value_local = float(tt.item())
-        gatherer = saved
+            rot.step(gather=False)
+        rot.fence(True)
+        value_local = max_over_ranks(time.perf_counter() - t1)
 
-    # ---- N > 1: what arrived on rank 0 is checked rank by rank against the MPDUs that rank's corpus was made from
-    # (the corpora are functions of the rank: rank 0 rebuilds every rank's expected PDUs)
+    # ---- what arrived on rank 0 is checked rank by rank against the MPDUs that rank's corpus was made from (the
+    # corpora are functions of the rank: rank 0 rebuilds every rank's expected PDUs)
     gather_check = None
-    if world > 1 and rank == 0 and gathered[0] is not None:
-        out_all, len_all = gathered[0]
+    if collective and rank == 0 and rot.gathered is not None:
+        got_all, len_all = rot.gathered
         per_rank = []
         for r in range(world):
             if args.workload == MIXED:
-                exp_r = payloads_mixed(tx, n, r)[3]
+                exp_r, idx_r = torch.from_numpy(payloads_mixed(tx, n, r)[3]), torch.arange(n)
+            elif args.workload == CAPTURE:
+                exp_r, idx_r = exp, idx  # every rank replicates the same sources
             elif args.unique > 0:
                 exp_r = None  # the replicated corpus keeps its payloads on the rank that drew them
             else:
-                exp_r = payloads_uniform(args.workload, n, r)[1]
-            rows = out_all[r * n:(r + 1) * n]
+                exp_r, idx_r = torch.from_numpy(payloads_uniform(args.workload, n, r)[1]), torch.arange(n)
             lens = len_all[r * n:(r + 1) * n]
-            got = (lens > 0)
-            rec = {"rank": r, "fcs_ok": int(got.sum().item())}
+            rows = shard.unpack_pdus(got_all[r], lens, out_stride) if compact else got_all[r * n:(r + 1) * n]
+            rec = {"rank": r, "fcs_ok": int((lens > 0).sum().item())}
+            if compact:
+                rec["bytes"] = int(got_all[r].numel())
             if exp_r is not None:
-                e = torch.from_numpy(exp_r).to(rows.device)
-                m = (rows[:, :e.shape[1]] == e).all(dim=1)
-                rec["bit_exact_vs_tx"] = int((got & m).sum().item())
-                rec["fcs_ok_but_wrong"] = int((got & ~m).sum().item())
+                c3 = check_rows(torch, rows, lens, exp_r.to(rows.device), idx_r.to(rows.device))
+                rec["bit_exact_vs_tx"], rec["fcs_ok_but_wrong"] = c3[1], c3[2]
             per_rank.append(rec)
         gather_check = {"ranks": per_rank, "slots_per_rank": n, "slot_bytes": out_stride,
-                        "note": "the PDU slots rank 0 holds after the last gather of the timed region, "
+                        "form": "blobs packed to their lengths (lengths gathered first, bytes point to point)" if compact
+                                else "fixed-stride slots, one gather",
+                        "backend": backend,
+                        "note": "the PDUs rank 0 holds after the last gather of the timed region, "
                                 "compared with the MPDUs each rank's corpus was generated from"}
 
     # ---- correctness of what was just timed: the results of the last step of every context (the first set is the one
@@ -510,33 +709,37 @@ def main():
     match = (out[:, :blob_len] == exp[idx]).all(dim=1)
     bitexact = int((match & ok_rows).sum().item())
     wrong = int((ok_rows & ~match).sum().item())
-    for o2, ol2, np2 in outs[1:min(depth, max(args.warmup, pipe) + args.steps)]:
+    for o2, ol2, np2 in rot.outs[1:min(rot.depth, max(args.warmup, pipe) + args.steps)]:
         if not (torch.equal(np2, n_pdu) and torch.equal(ol2, out_len) and torch.equal(o2[:, :blob_len], out[:, :blob_len])):
             raise RuntimeError("the contexts of the pipeline disagree about the same batch")
+
+    def one_step(c, no_wait=False):
+        for a0, a1, d_, npart, lo, _ in parts:
+            c.rx_batch_into(a0, a1, d_, npart, out[lo:lo + npart], out_len[lo:lo + npart], n_pdu[lo:lo + npart], no_wait=no_wait)
 
     # ---- the same steps one batch at a time (one context, each step queued behind the one before): the figure the
     # pipelined rate is to be compared with
     serial_ms = None
     if pipe > 1:
-        fence()
+        rot.fence(collective)
         t1 = time.perf_counter()
-        with torch.cuda.stream(streams[0]):
+        with torch.cuda.stream(rot.streams[0]):
             for _ in range(args.steps):
-                ctx.rx_batch_into(arena, arena1, desc, n, out, out_len, n_pdu, no_wait=True)
-        fence()
+                one_step(rot.ctxs[0], no_wait=True)
+        rot.fence(collective)
         serial_ms = (time.perf_counter() - t1) / args.steps * 1e3
-        if ctx.last_batch_refused():
+        if rot.ctxs[0].last_batch_refused():
             raise RuntimeError("a batch queued without the wait found too little room")
 
     # ---- the same steps with several batches in flight: one context per batch, each on the stream it created (these
     # land on hardware queues of their own; streams from torch's pool were seen to share one), one host thread each.
     # While one batch's decoder drains, the next batch's kernels take the SIMDs that fall idle.  Not the headline.
     in_flight = None
-    if world == 1 and args.in_flight > 1:
+    if not collective and args.in_flight > 1 and len(parts) == 1:
         try:
             import threading
             depth_f = args.in_flight
-            fctxs = [ctx] + [pkg.RxContext(local) for _ in range(depth_f - 1)]
+            fctxs = rot.ctxs[:depth_f] + [pkg.RxContext(local) for _ in range(depth_f - len(rot.ctxs[:depth_f]))]
             fouts = [(out, out_len, n_pdu)] + [tuple(torch.zeros_like(t) for t in (out, out_len, n_pdu))
                                                 for _ in range(depth_f - 1)]
             errors = []
@@ -548,13 +751,13 @@ def main():
                     if delay > 0:
                         time.sleep(delay)
                     for _ in range(steps):
-                        fctxs[k].rx_batch_into(arena, arena1, desc, n, *fouts[k])
+                        fctxs[k].rx_batch_into(arena, arena1, parts[0][2], n, *fouts[k])
                     fctxs[k].sync()
                 except Exception as e:  # noqa: BLE001 - reported from the main thread
                     errors.append(repr(e))
 
-            for k in range(1, depth_f):
-                flight(k, 2)  # the new contexts' work buffers reach their size
+            for k in range(depth_f):
+                flight(k, 2)  # the contexts' work buffers reach their size
             per = max(4, (args.steps + depth_f - 1) // depth_f)
             torch.cuda.synchronize()
             threads = [threading.Thread(target=flight, args=(k, per, k * stagger)) for k in range(depth_f)]
@@ -574,7 +777,7 @@ def main():
                 exact.append([int(rows.sum().item()), int((rows & m).sum().item()), int((rows & ~m).sum().item())])
             in_flight = {"contexts": depth_f, "steps": per * depth_f, "ms_per_step": dtf / (per * depth_f) * 1e3,
                          "fcs_ok__bit_exact__wrong_per_context": exact}
-            for c in fctxs[1:]:
+            for c in fctxs[len(rot.ctxs):]:
                 c.close()
             del fouts, fctxs
         except Exception as e:  # noqa: BLE001 - this leg is an extra: the headline line is printed whatever happens here
@@ -582,11 +785,11 @@ def main():
 
     # ---- per-kernel durations from HIP events on the launch stream (untimed extra steps)
     timing = {}
-    if args.profile_steps > 0:
+    if args.profile_steps > 0 and len(parts) == 1:
         ctx.set_profiling(True)
         acc = {}
         for _ in range(args.profile_steps):
-            ctx.rx_batch_into(arena, arena1, desc, n, out, out_len, n_pdu)
+            one_step(ctx)
             for k, v in ctx.last_timing().items():
                 acc[k] = acc.get(k, 0.0) + v
         ctx.set_profiling(False)
@@ -598,18 +801,24 @@ def main():
         "metric": "RX Msamples/s (demod+Viterbi) per GPU + %HBM-roofline; PSDU bit-exact",
         "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": "f32", "data": "synthetic" if cap is None else "the reference's IQ fixtures and generator frames, replicated",
         "config": {"workload": args.workload, "frames_per_gpu": n, "samples_per_frame": L,
                    "format": "VHT" if fmt == 2 else "HT" if fmt == 1 else "L" if fmt == 0 else "L/HT/VHT in rotation",
-                   "mcs": mcs if extra is None else [list(k) for k in MIXED_KINDS], "n_rx": nss,
+                   "mcs": mcs if extra is None else ([list(k) for k in MIXED_KINDS] if cap is None else cap["source_kinds"]),
+                   "n_rx": nss if cap is None else "1 and 2",
                    "psdu_bytes": nbytes + 4 if fmt == 2 else nbytes, "snr_db": snr_db, "unique_payloads": args.unique if args.unique > 0 else n,
                    "parallelism": ("frames sharded per rank, gather of MPDUs to rank 0 over %s" %
                                    ("RCCL" if backend == "nccl" else backend + " (host-staged rehearsal, ranks share GPUs)"))
-                   if world > 1 else "single GPU",
+                   if collective else "single GPU",
                    "batches_in_flight": pipe, "hw_queues": queues},
         "psdu": {"frames": n, "fcs_ok": n_ok, "bit_exact_vs_tx": bitexact, "fcs_ok_but_wrong": wrong},
         "kernel_ms": timing,
     }
+    if timing and pipe > 1:
+        res["kernels_overlap_across_steps"] = True
+        res["kernel_ms_note"] = ("kernel_ms: separate steps on one context, nothing beside them (HIP events); ms_per_step: "
+                                 "steps rotating over %d contexts whose kernels overlap, so a kernel's time alone can exceed "
+                                 "a step's share of the rotation" % pipe)
     if serial_ms is not None:
         res["one_batch_at_a_time"] = {"ms_per_step": serial_ms, "value": samples_per_step / serial_ms / 1e3,
                                       "unit": "Msamples/s",
@@ -633,7 +842,7 @@ def main():
     # forward pass and traceback run as one kernel (k_decode); when the library is switched to the
     # two-kernel form the two slots add up to the same work
     dec_ms = timing.get("viterbi", 0.0) + timing.get("traceback", 0.0)
-    if dec_ms > 0:
+    if dec_ms > 0 and (extra is None or extra.get("total_steps")):
         timing["decode"] = dec_ms
         dur = dec_ms * 1e-3
         steps_per_frame = TRELLIS_STEPS[args.workload] if extra is None else extra["total_steps"] / n
@@ -643,6 +852,7 @@ def main():
         traffic = None
         if "FETCH_SIZE_KiB" in kd and "WRITE_SIZE_KiB" in kd:
             # gfx950 tallies the 128-byte read requests of wide streaming loads at 64 bytes: FETCH_SIZE is doubled
+            # (pinned by tools/ubench/hbm.hip under --pmc: a read of known size counts half, profiles/r03_fetch_size_check.txt)
             traffic = 2.0 * kd["FETCH_SIZE_KiB"] * 1024.0 + kd["WRITE_SIZE_KiB"] * 1024.0
         hbm = b_alg * n / dur / 1e9
         tflops = FLOP_PER_STATE_UPDATE * updates / dur / 1e12
@@ -657,8 +867,10 @@ def main():
                            "hbm": {"achieved": hbm, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm / HBM_PEAK_GBS,
                                    "algorithmic_bytes_per_frame": b_alg, "traffic_bytes_per_launch": traffic,
                                    "traffic_over_algorithmic": (traffic / (b_alg * n)) if traffic else None,
+                                   "counters_raw": {k: kd[k] for k in ("FETCH_SIZE_KiB", "WRITE_SIZE_KiB") if k in kd},
                                    "note": "IQ in + PSDU out per frame; the launch also reads the soft bits the "
-                                           "demodulator materialised and writes and reads the survivor words"}}
+                                           "demodulator materialised and writes and reads the survivor words; traffic = "
+                                           "2 x FETCH_SIZE + WRITE_SIZE (the raw counters are beside it)"}}
         # vector-instruction issue, the resource that binds: every figure but the last two comes from counters of
         # the profiled launch (rocprofv3 passes under profiles/, same workload and batch size) and from this run's
         # own kernel duration
@@ -699,10 +911,11 @@ def main():
             tr = (2.0 * km["FETCH_SIZE_KiB"] + km["WRITE_SIZE_KiB"]) * 1024.0 if "FETCH_SIZE_KiB" in km and "WRITE_SIZE_KiB" in km else None
             res["roofline"]["k_demod"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                           "frac": ach / HBM_PEAK_GBS, "algorithmic_bytes_per_frame": b_demod, "traffic": tr,
+                                          "counters_raw": {k: km[k] for k in ("FETCH_SIZE_KiB", "WRITE_SIZE_KiB") if k in km},
                                           "copy_kernel_gbs": COPY_KERNEL_GBS,
                                           "note": "copy_kernel_gbs: what a plain device-to-device copy kernel sustains "
                                                   "on this chip (tools/ubench/hbm.hip, profiles/r02_hbm_ubench.txt)"}
-    if rank == 0 and world == 1 and args.detect and extra is None:
+    if rank == 0 and not collective and args.detect and extra is None:
         # raw capture in: frame detection (presiso -> trigger -> sync) finds the frames, `signal`'s trigger search
         # picks the ones it deals with, then the same RX kernels run; reported beside the headline, which starts
         # from given descriptors
@@ -734,16 +947,17 @@ def main():
                          "bit_exact_vs_tx": int((okd & md).sum().item()),
                          "fcs_ok_but_wrong": int((okd & ~md).sum().item())}
         del r
-    if rank == 0 and world == 1 and args.host_buffers:
+    if rank == 0 and not collective and args.host_buffers and len(parts) == 1:
         # the same step when the boundary hands over host buffers: IQ travels H2D, PDUs travel D2H (pinned memory)
-        h_in = [a.cpu().pin_memory() for a in arenas]
+        arenas_ = [a for a in (arena, arena1) if a is not None]
+        h_in = [a.cpu().pin_memory() for a in arenas_]
         h_out = torch.empty(out.shape, dtype=out.dtype).pin_memory()
         h_len = torch.empty(out_len.shape, dtype=out_len.dtype).pin_memory()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for a, h in zip(arenas, h_in):
+        for a, h in zip(arenas_, h_in):
             a.copy_(h, non_blocking=True)
-        ctx.rx_batch_into(arena, arena1, desc, n, out, out_len, n_pdu)
+        one_step(ctx)
         h_out.copy_(out, non_blocking=True)
         h_len.copy_(out_len, non_blocking=True)
         torch.cuda.synchronize()
@@ -751,18 +965,61 @@ def main():
         res["host_buffers"] = {"value": samples_per_step / world / dth / 1e6, "unit": "Msamples/s", "ms_per_step": dth * 1e3,
                                "note": "IQ arena H2D + step + PDU slots D2H over PCIe, pinned host memory; not the headline"}
         del h_in, h_out, h_len
-    if rank == 0 and args.cpu_frames > 0 and world == 1:
+
+    # ---- BASELINE.json configs[4] beside the headline: the capture corpus, sharded like everything else (every rank
+    # its 125 000 replicas), MPDUs gathered on rank 0 packed to their lengths
+    want_cap = args.capture_corpus == 1 or (args.capture_corpus < 0 and world == 8)
+    if want_cap and args.workload != CAPTURE:
+        rot.close()
+        del rot, out, out_len, n_pdu
+        torch.cuda.empty_cache()
+        ncap = DEFAULT_FRAMES[CAPTURE]
+        cc = build_corpus_capture(torch, ctx, ncap, dev)
+        stride_c = ((cc["blob_len"] + 4 + 63) // 64) * 64
+        rc = Rotation(torch, dist, pkg, shard, local, dev, cc["parts"], ncap, stride_c, pipe, collective, args.gather != "fixed", ctx)
+        steps_c = max(4, args.steps // 2)
+        dtc = max_over_ranks(rc.timed(steps_c, args.warmup, collective))
+        o_c, ol_c, np_c = rc.outs[0]
+        c3 = check_rows(torch, o_c, ol_c, cc["exp"], cc["idx"])
+        rec = {"workload": CAPTURE, "value": cc["total_samples"] * world * steps_c / dtc / 1e6, "unit": "Msamples/s",
+               "ms_per_step": dtc / steps_c * 1e3, "steps": steps_c, "frames_per_gpu": ncap, "sources": cc["sources"],
+               "source_kinds__format_mcs_antennas_mpdu_bytes": cc["source_kinds"],
+               "algorithmic_bytes_per_frame": cc["b_alg"],
+               "psdu": {"frames": ncap, "fcs_ok": c3[0], "bit_exact_vs_fixture_mpdu": c3[1], "fcs_ok_but_wrong": c3[2]},
+               "note": "the reference's tools/sig80211GenMultiple*.bin and the frames of its Python generator "
+                       "(tests/golden), replicated round-robin; one- and two-antenna frames are the two calls of a step"}
+        if collective and rank == 0 and rc.gathered is not None:
+            got_all, len_all = rc.gathered
+            per_rank = []
+            for r in range(world):
+                lens = len_all[r * ncap:(r + 1) * ncap]
+                rows = (shard.unpack_pdus(got_all[r], lens, stride_c) if rc.compact else got_all[r * ncap:(r + 1) * ncap])
+                k3 = check_rows(torch, rows, lens, cc["exp"].to(rows.device), cc["idx"].to(rows.device))
+                per_rank.append({"rank": r, "fcs_ok": k3[0], "bit_exact_vs_fixture_mpdu": k3[1], "fcs_ok_but_wrong": k3[2],
+                                 "bytes": int(got_all[r].numel()) if rc.compact else ncap * stride_c})
+            rec["gathered_on_rank0"] = {"ranks": per_rank, "fixed_stride_bytes_per_rank": ncap * stride_c,
+                                        "form": "packed to lengths" if rc.compact else "fixed stride"}
+        res["capture_corpus"] = rec
+        rc.close()
+        del rc, cc
+
+    if rank == 0 and args.cpu_frames > 0 and not collective and sync is not None:
         ns = min(args.cpu_frames, n)
         upto = int(sync[ns - 1]) + int(navail[ns - 1]) + 64  # the first ns frames end here
         host = arena[:upto].cpu().numpy()
         host1 = arena1[:upto].cpu().numpy() if arena1 is not None else None
-        lens = out_len[:ns].cpu().numpy()
-        rows = out[:ns].cpu().numpy()
+        o_, ol_, np_ = (torch.zeros((n, out_stride), dtype=torch.uint8, device=dev), torch.zeros(n, dtype=torch.int32, device=dev),
+                        torch.zeros(n, dtype=torch.int32, device=dev))
+        ctx.rx_batch_into(arena, arena1, parts[0][2], n, o_, ol_, np_)
+        ctx.sync()
+        lens = ol_[:ns].cpu().numpy()
+        rows = o_[:ns].cpu().numpy()
         gpu_blobs = [bytes(rows[i, : lens[i]]) for i in range(ns)]
         res["cpu_baseline"] = cpu_baseline(host, host1, sync, navail, ns, gpu_blobs)
     if rank == 0:
         print(json.dumps(res))
-    if world > 1:
+        sys.stdout.flush()
+    if collective:
         dist.barrier()
         dist.destroy_process_group()
     ctx.close()

@@ -46,6 +46,7 @@ struct gr80211_ctx {
     Buf det_mask, det_blk, det_runs, det_rec, det_totals_d, cap_desc, cap_ws;
     Buf tx_desc, sig_desc, chanl, out_off;
     Buf info_alt, chan1_alt, chan2_alt;  // the capture path's second set of frame records and channels
+    Buf pack_ws;                         // gr80211_pack_pdus: per-frame offsets and per-block sums
     // a batch between gr80211_rx_submit and gr80211_rx_finish
     struct {
         bool active;
@@ -559,6 +560,91 @@ void launch_link_copy(void *dst, const void *src, size_t bytes, unsigned *finish
 }
 }  // namespace
 
+
+namespace {
+// ---- gr80211_pack_pdus: the PDU slots of a batch as one run of bytes, each frame's blob rounded up to 16 bytes.
+// Three small kernels: padded sizes scanned inside blocks of 1024 frames, the block sums scanned by one workgroup,
+// then one wave per frame copies its blob to its place.
+constexpr int PACK_BLOCK = 1024;
+__device__ __forceinline__ unsigned pack_pad16(int len) { return len > 0 ? ((unsigned)len + 15u) & ~15u : 0u; }
+
+__global__ __launch_bounds__(PACK_BLOCK) void k_pack_sizes(const int32_t *__restrict__ out_len, int n, int stride,
+                                                            unsigned long long *__restrict__ off, unsigned long long *__restrict__ blk)
+{
+    __shared__ unsigned wsum[PACK_BLOCK / 64];
+    const int i = blockIdx.x * PACK_BLOCK + threadIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int len = i < n ? out_len[i] : 0;
+    if (len > stride) len = stride;  // a slot never holds more than its stride
+    const unsigned mine = pack_pad16(len);
+    unsigned incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned o = __shfl_up(incl, d);
+        if (lane >= d) incl += o;
+    }
+    if (lane == 63) wsum[w] = incl;
+    __syncthreads();
+    unsigned before = 0;
+    for (int k = 0; k < w; k++) before += wsum[k];
+    if (i < n) off[i] = (unsigned long long)(before + incl - mine);
+    if (threadIdx.x == PACK_BLOCK - 1) blk[blockIdx.x] = (unsigned long long)(before + incl);
+}
+
+__global__ __launch_bounds__(1024) void k_pack_scan_blocks(unsigned long long *__restrict__ blk, int nblk,
+                                                            unsigned long long *__restrict__ total)
+{
+    // nblk <= 1024 (at most 2^20 frames per call): one element per thread
+    __shared__ unsigned long long wsum[16];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const unsigned long long mine = t < nblk ? blk[t] : 0ull;
+    unsigned long long incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned long long o = __shfl_up(incl, d);
+        if (lane >= d) incl += o;
+    }
+    if (lane == 63) wsum[w] = incl;
+    __syncthreads();
+    unsigned long long before = 0;
+    for (int k = 0; k < w; k++) before += wsum[k];
+    if (t < nblk) blk[t] = before + incl - mine;
+    if (t == 1023) *total = before + incl;
+}
+
+__global__ __launch_bounds__(256) void k_pack_copy(const uint8_t *__restrict__ out, int stride, const int32_t *__restrict__ out_len,
+                                                   int n, const unsigned long long *__restrict__ off,
+                                                   const unsigned long long *__restrict__ blk, uint8_t *__restrict__ packed,
+                                                   unsigned long long cap, unsigned long long *__restrict__ off_out)
+{
+    const int f = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (f >= n) return;
+    int len = out_len[f];
+    if (len > stride) len = stride;
+    const unsigned padded = pack_pad16(len);
+    const unsigned long long at = blk[f / PACK_BLOCK] + off[f];
+    if (off_out && lane == 0) off_out[f] = at;
+    if (padded == 0 || at + padded > cap) return;  // no room: the caller sees total > cap
+    const pull_u4 *src = reinterpret_cast<const pull_u4 *>(out + (size_t)f * stride);
+    pull_u4 *dst = reinterpret_cast<pull_u4 *>(packed + at);
+    const int nq = (int)(padded / 16);
+    for (int q = lane; q < nq; q += 64) {
+        pull_u4 v = src[q];
+        // bytes between the blob's end and the 16-byte boundary leave as zeros, whatever the slot held there
+        const int left = len - q * 16;
+        if (left < 16) {
+            unsigned wv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int lb = left - 4 * k;
+                wv[k] = lb >= 4 ? wv[k] : lb <= 0 ? 0u : wv[k] & ((1u << (8 * lb)) - 1u);
+            }
+            v.x = wv[0], v.y = wv[1], v.z = wv[2], v.w = wv[3];
+        }
+        dst[q] = v;
+    }
+}
+}  // namespace
+
 extern "C" {
 
 const char *gr80211_version(void) { return "gr80211_rx 0.1 (gfx950)"; }
@@ -622,7 +708,7 @@ void gr80211_destroy(gr80211_ctx *c)
     for (Buf *b : {&c->desc, &c->ddesc, &c->info, &c->chan1, &c->chan2, &c->llr, &c->slot_frame, &c->groups, &c->dec,
                    &c->bitsw, &c->totals_d, &c->sched_ws, &c->blk_llr, &c->det_mask, &c->det_blk, &c->det_runs,
                    &c->det_rec, &c->det_totals_d, &c->cap_desc, &c->cap_ws, &c->tx_desc, &c->sig_desc, &c->chanl, &c->out_off,
-                   &c->info_alt, &c->chan1_alt, &c->chan2_alt, &c->sel_index})
+                   &c->info_alt, &c->chan1_alt, &c->chan2_alt, &c->sel_index, &c->pack_ws})
         release(*b);
     for (auto &e : c->mark_ev)
         if (e) (void)hipEventDestroy(e);
@@ -1110,6 +1196,29 @@ int gr80211_rx_resume(gr80211_ctx *c, const void *d_iq0, const void *d_iq1, uint
     if (d_info)
         HIP_TRY(c, hipMemcpyAsync(d_info, c->info.p, (size_t)n * sizeof(gr80211_frame_info), hipMemcpyDeviceToDevice, s));
     return finish_timing(c, s);
+}
+
+int gr80211_pack_pdus(gr80211_ctx *c, const uint8_t *d_out, int out_stride, const int32_t *d_out_len, int n, uint8_t *d_packed,
+                      uint64_t packed_cap, uint64_t *d_total, uint64_t *d_off, void *stream)
+{
+    if (!c) return GR80211_ERR_ARG;
+    if (n < 0 || !d_total || (n > 0 && (!d_out || !d_out_len || !d_packed)) || out_stride < 16 || (out_stride & 15) ||
+        ((uintptr_t)d_out & 15) || ((uintptr_t)d_packed & 15))
+        return fail(c, GR80211_ERR_ARG, "gr80211_pack_pdus: bad argument (slots and packed run 16-byte aligned, stride a multiple of 16)");
+    if (n > (1 << 20)) return fail(c, GR80211_ERR_ARG, "gr80211_pack_pdus: at most 1048576 frames per call");
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = pick(c, stream);
+    const int nblk = (n + PACK_BLOCK - 1) / PACK_BLOCK;
+    int rc = ensure(c, c->pack_ws, ((size_t)n + 1024 + 8) * sizeof(unsigned long long));
+    if (rc) return rc;
+    unsigned long long *off = (unsigned long long *)c->pack_ws.p, *blk = off + n;
+    if (nblk > 0) hipLaunchKernelGGL(k_pack_sizes, dim3(nblk), dim3(PACK_BLOCK), 0, s, d_out_len, n, out_stride, off, blk);
+    hipLaunchKernelGGL(k_pack_scan_blocks, dim3(1), dim3(1024), 0, s, blk, nblk, (unsigned long long *)d_total);
+    if (n > 0)
+        hipLaunchKernelGGL(k_pack_copy, dim3((n + 3) / 4), dim3(256), 0, s, d_out, out_stride, d_out_len, n, off, blk, d_packed,
+                           (unsigned long long)packed_cap, (unsigned long long *)d_off);
+    HIP_TRY(c, hipGetLastError());
+    return GR80211_OK;
 }
 
 int gr80211_last_batch_refused(gr80211_ctx *c)

@@ -75,7 +75,7 @@ EXPORTS = [
     "gr80211_rx_submit", "gr80211_rx_finish", "gr80211_decode_batch_noalloc", "gr80211_rx_resume",
     "gr80211_last_batch_refused", "gr80211_copy_h2d_async", "gr80211_copy_d2h_async", "gr80211_copy_d2d_async", "gr80211_pull_h2d", "gr80211_pull_done", "gr80211_push_d2h", "gr80211_get_stream",
     "gr80211_stream_idle", "gr80211_stream_wait", "gr80211_marker_record", "gr80211_marker_done",
-    "gr80211_host_register", "gr80211_host_unregister",
+    "gr80211_host_register", "gr80211_host_unregister", "gr80211_pack_pdus",
 ]
 
 _lib = None
@@ -126,6 +126,7 @@ def load_library():
     L.gr80211_host_register.argtypes = [vp, vp, C.c_size_t]
     L.gr80211_host_unregister.argtypes = [vp, vp]
     L.gr80211_decode_batch_noalloc.argtypes = [vp, vp, C.c_uint64, vp, C.c_int, vp, C.c_int, vp, vp, vp, C.c_int, vp]
+    L.gr80211_pack_pdus.argtypes = [vp, vp, C.c_int, vp, C.c_int, vp, C.c_uint64, vp, vp, vp]
     L.gr80211_dev_alloc.argtypes = [vp, C.c_size_t]
     L.gr80211_dev_alloc.restype = vp
     L.gr80211_host_alloc.argtypes = [vp, C.c_size_t]
@@ -467,6 +468,16 @@ class RxContext:
             C.c_void_p(bits.data_ptr()) if bits is not None else None, bits.shape[1] if bits is not None else 0,
             self._stream())
         self._check(rc, "gr80211_decode_batch_noalloc")
+
+    def pack_pdus(self, out, out_len, packed, total, off=None):
+        """gr80211_pack_pdus: the PDU slots out [n, stride] / out_len [n] as one run of bytes in `packed` (uint8 CUDA
+        tensor), every blob rounded up to 16 bytes; total: uint64-sized CUDA tensor of one element (int64) that
+        receives the run's length; off (optional, int64 [n]): where each blob starts.  Queued on the current stream."""
+        rc = self.lib.gr80211_pack_pdus(
+            self.h, C.c_void_p(out.data_ptr()), out.shape[1], C.c_void_p(out_len.data_ptr()), out.shape[0],
+            C.c_void_p(packed.data_ptr()), packed.numel(), C.c_void_p(total.data_ptr()),
+            C.c_void_p(off.data_ptr()) if off is not None else None, self._stream())
+        self._check(rc, "gr80211_pack_pdus")
 
     # -- transmitter ---------------------------------------------------------------------
     @staticmethod

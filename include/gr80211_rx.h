@@ -379,6 +379,19 @@ int gr80211_demod_tagged_batch(gr80211_ctx *ctx, const void *d_iq0, const void *
                                const gr80211_sig_desc *desc, int n_frames, unsigned flags, const void *d_chan,
                                gr80211_frame_info *d_info, const float **d_llr, uint64_t *llr_floats, void *stream);
 
+/*
+ * The PDU slots of a batch as one contiguous run of bytes, for the one exchange step of a multi-GPU receiver (decoded
+ * MPDUs gathered on one rank): frame i's blob (d_out_len[i] bytes of slot i, the layout `decode` publishes,
+ * lib/decode_impl.cc:512-516) lies at d_packed + off[i], off = exclusive prefix sum of the lengths rounded up to 16
+ * bytes (the bytes between a blob's end and the boundary are zeros); frames without a PDU take no room.  The receiver
+ * rebuilds off from the gathered d_out_len.  *d_total (device, required) = bytes of the run; blobs that would reach
+ * past packed_cap are not written (d_total then exceeds packed_cap).  d_off (nullable, device, n entries) receives off.
+ * d_out and d_packed 16-byte aligned, out_stride a multiple of 16.  The reference has no counterpart: its `decode`
+ * publishes one message per MPDU to a message port (lib/decode_impl.cc:414-419).
+ */
+int gr80211_pack_pdus(gr80211_ctx *ctx, const uint8_t *d_out, int out_stride, const int32_t *d_out_len, int n_frames,
+                      uint8_t *d_packed, uint64_t packed_cap, uint64_t *d_total, uint64_t *d_off, void *stream);
+
 /* Device memory helpers so that a C / FFI caller needs no HIP binding of its own. */
 void *gr80211_dev_alloc(gr80211_ctx *ctx, size_t bytes);
 void gr80211_dev_free(gr80211_ctx *ctx, void *p);

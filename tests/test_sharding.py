@@ -130,3 +130,81 @@ def test_gather_two_ranks_gloo():
         p.join(120)
         assert p.exitcode == 0
     assert q.get(timeout=5) is True
+
+
+def _worker_compact(rank, world, port, n_local, q):
+    """Three batches of blobs of unequal lengths through the length-compacted gather: rank 0 must end up with
+    every rank's blobs, byte for byte, and with no more bytes than the padded lengths add up to."""
+    sys.path.insert(0, ROOT)
+    import importlib
+    shard = importlib.import_module("fork-gr-ieee80211_amd.shard")
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    stride, depth = 64, 2
+    g = shard.PduGatherCompact(n_local, stride, torch.device("cpu"), shard.pack_pdus_host, dst=0, depth=depth)
+
+    def batch(r, step):
+        gen = torch.Generator().manual_seed(1000 * r + step)
+        out = torch.randint(0, 256, (n_local, stride), dtype=torch.uint8, generator=gen)
+        lens = torch.randint(0, stride + 1, (n_local,), dtype=torch.int32, generator=gen)
+        lens[::7] = 0  # frames without a PDU
+        if r == 1 and step == 1:
+            lens[:] = 0  # a rank with nothing to send
+        return out, lens
+
+    ok, seen = True, []
+    for step in range(3):
+        slot = step % depth
+        res = g.wait(slot)
+        if res[0] is not None:
+            seen.append((step - depth, [v.clone() for v in res[0]], res[1].clone()))
+        o, ol = batch(rank, step)
+        g.start(slot, o, ol)
+    for step in (3, 4):
+        res = g.wait(step % depth)
+        if res[0] is not None:
+            seen.append((step - depth, [v.clone() for v in res[0]], res[1].clone()))
+    if rank == 0:
+        ok = sorted(s for s, _, _ in seen) == [0, 1, 2]
+        for step, runs, lens_all in seen:
+            for r in range(world):
+                o, ol = batch(r, step)
+                lens = lens_all[r * n_local:(r + 1) * n_local]
+                ok = ok and torch.equal(lens, ol)
+                ok = ok and runs[r].numel() == int(shard.pad16(ol.to(torch.int64)).sum())
+                rows = shard.unpack_pdus(runs[r], lens, stride)
+                keep = torch.arange(stride)[None, :] < ol[:, None]
+                ok = ok and torch.equal(rows, torch.where(keep, o, torch.zeros((), dtype=torch.uint8)))
+        q.put(bool(ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_compact_gather_two_ranks_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_compact, args=(r, 2, port, 50, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert q.get(timeout=5) is True
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` without a launcher and without WORLD_SIZE starts torch.distributed.run itself,
+    before anything touches a GPU.  No GPU here: the ranks get as far as selecting a device and fail there, and
+    the parent leaves with the launcher's (non-zero) exit code instead of the old refusal."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+                        "--frames", "64"], env=env, capture_output=True, text=True, timeout=300)
+    if torch.cuda.is_available():
+        assert r.returncode == 0, r.stderr[-2000:]
+        return
+    assert r.returncode != 0
+    assert "must be launched with" not in (r.stdout + r.stderr)
+    assert "torch.distributed" in r.stderr or "ChildFailedError" in r.stderr or "rank" in r.stderr.lower()
