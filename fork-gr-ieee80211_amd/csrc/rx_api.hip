@@ -65,6 +65,8 @@ struct gr80211_ctx {
     uint32_t *pull_flag_h = nullptr;        // pinned: number of the last gr80211_pull_h2d copy that has read all of its source
     unsigned *pull_ctr_d = nullptr;         // device: workgroups of the running pull copy that have finished
     long long pull_seq = 0;
+    hipStream_t pull_stream = nullptr;      // the one stream this context's pull copies go to (they share a counter and a flag)
+    bool pull_stream_set = false;
     void *pull_flag_view = nullptr;         // the flag word as the GPU addresses it
     // Descriptors the caller keeps in ordinary host memory travel through page-locked memory of the context: the
     // runtime's copy from ordinary memory waits for everything its hardware queue holds, other streams' decoders included.
@@ -245,14 +247,18 @@ bool decoder_admits(int cr, int trellis, int len, long long n_llr)
 }
 
 // Shared tail, first half: the scheduler's kernels and the copy of its totals to the host, all asynchronous.
-int launch_sched_stage(gr80211_ctx *c, hipStream_t s, int n, bool from_iq, SchedCaps caps = SCHED_NO_CAPS)
+// max_groups >= 0: the decoder will be launched for that many groups (the host worked the count out itself); the
+// scheduler is told, so that a batch for which the device arrives at more is marked as refused instead of being
+// decoded in part.
+int launch_sched_stage(gr80211_ctx *c, hipStream_t s, int n, bool from_iq, SchedCaps caps = SCHED_NO_CAPS, int max_groups = -1)
 {
     if (c->pending.active) return fail(c, GR80211_ERR_ARG, "a batch submitted with gr80211_rx_submit is waiting for gr80211_rx_finish");
     const int slot_cap = n + 4 * 64 + 64;
-    const int group_cap = slot_cap / 64 + 1;
+    const int group_room = slot_cap / 64 + 1;  // what the group array holds
+    const int group_cap = max_groups >= 0 && max_groups < group_room ? max_groups : group_room;
     int rc;
     if ((rc = ensure(c, c->slot_frame, (size_t)slot_cap * sizeof(int32_t)))) return rc;
-    if ((rc = ensure(c, c->groups, (size_t)group_cap * sizeof(GroupInfo)))) return rc;
+    if ((rc = ensure(c, c->groups, (size_t)group_room * sizeof(GroupInfo)))) return rc;
     if ((rc = ensure(c, c->totals_d, sizeof(SchedTotals)))) return rc;
     if ((rc = ensure(c, c->sched_ws, (size_t)SCHED_WS_WORDS * sizeof(uint32_t)))) return rc;
     if ((rc = ensure(c, c->blk_llr, (size_t)(n / 256 + 2) * sizeof(unsigned long long)))) return rc;
@@ -293,7 +299,7 @@ int finish_decode_stages(gr80211_ctx *c, hipStream_t s, int n, bool from_iq, con
     mark(c, 3, s);
     if (decode) {
         launch_clear_outputs(d_out_len, d_n_pdu, n, s);
-        if (from_iq && !d_iq1) launch_ndp_emit(d_iq0, arena_len, d_desc, n, info, d_out, out_stride, d_out_len, d_n_pdu, s);
+        if (from_iq && !d_iq1) launch_ndp_emit(d_iq0, arena_len, d_desc, n, info, d_out, out_stride, d_out_len, d_n_pdu, dt, s);
         if (tot.n_groups > 0) {
             if ((rc = ensure(c, c->dec, (size_t)(tot.dec_words + 128) * sizeof(uint32_t)))) return rc;
             if ((rc = ensure(c, c->bitsw, (size_t)(tot.bits_words + 64) * sizeof(uint32_t)))) return rc;
@@ -365,7 +371,7 @@ int run_decode_stages(gr80211_ctx *c, hipStream_t s, int n, bool from_iq, const 
         caps.dec_words = decode ? (c->dec.cap >= 128 * sizeof(uint32_t) ? c->dec.cap / sizeof(uint32_t) - 128 : 0) : ~0ull;
         caps.bits_words = decode ? (c->bitsw.cap >= 64 * sizeof(uint32_t) ? c->bitsw.cap / sizeof(uint32_t) - 64 : 0) : ~0ull;
     }
-    if ((rc = launch_sched_stage(c, s, n, from_iq, caps))) return rc;
+    if ((rc = launch_sched_stage(c, s, n, from_iq, caps, known ? known->n_groups : -1))) return rc;
     return finish_decode_stages(c, s, n, from_iq, d_iq0, d_iq1, arena_len, d_desc, d_llr_in, d_out, out_stride, d_out_len,
                                 d_n_pdu, d_bits, bits_stride, decode, llr_used, llr_floats, known);
 }
@@ -1248,6 +1254,14 @@ long long gr80211_pull_h2d(gr80211_ctx *c, void *d_dst, const void *h_src, size_
         *c->pull_flag_h = 0;
         if (hipHostGetDevicePointer(&c->pull_flag_view, c->pull_flag_h, 0) != hipSuccess) return fail(c, GR80211_ERR_HIP, "hipHostGetDevicePointer");
     }
+    // one finished-workgroup counter and one flag word per context: two pull kernels running at once on different
+    // streams would share them, so a context's pulls all go to the stream the first one went to
+    if (!c->pull_stream_set) {
+        c->pull_stream = pick(c, stream);
+        c->pull_stream_set = true;
+    } else if (c->pull_stream != pick(c, stream)) {
+        return fail(c, GR80211_ERR_ARG, "gr80211_pull_h2d: a context's pull copies all go to one stream (use another context for another stream)");
+    }
     // the last range that matched is tried first (a stream buffer is used call after call)
     void *dev_view = nullptr;
     const uintptr_t a = (uintptr_t)h_src;
@@ -1284,7 +1298,7 @@ int gr80211_pull_done(gr80211_ctx *c, long long number, int wait)
     for (long spins = 0; (int32_t)(*f - (uint32_t)number) < 0; spins++) {
         if (spins > 2000 && (spins & 1023) == 0) {
             // a copy that takes this long may be behind work that has failed: ask the runtime
-            const hipError_t e = hipStreamQuery(c->stream);
+            const hipError_t e = hipStreamQuery(c->pull_stream_set ? c->pull_stream : c->stream);
             if (e != hipSuccess && e != hipErrorNotReady) return fail(c, GR80211_ERR_HIP, "gr80211_pull_done", e);
             if (e == hipSuccess && (int32_t)(*f - (uint32_t)number) < 0 && spins > 200000000)
                 return fail(c, GR80211_ERR_HIP, "gr80211_pull_done: the copy's number never arrived");

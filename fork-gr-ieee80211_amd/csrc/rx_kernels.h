@@ -90,7 +90,7 @@ void launch_decode_split2(const float *llr, const gr80211_frame_info *info, cons
                           int32_t *n_pdu, uint8_t *bits_out, int bits_stride, int strict, const SchedTotals *totals, hipStream_t s);
 void launch_ndp_emit(const void *iq0, uint64_t arena_len, const gr80211_frame_desc *desc, int n,
                      const gr80211_frame_info *info, uint8_t *out, int out_stride, int32_t *out_len, int32_t *n_pdu,
-                     hipStream_t s);
+                     const SchedTotals *totals, hipStream_t s);
 void launch_clear_outputs(int32_t *out_len, int32_t *n_pdu, int n, hipStream_t s);
 
 }  // namespace gr80211

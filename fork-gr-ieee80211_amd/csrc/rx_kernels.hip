@@ -1938,10 +1938,11 @@ __global__ __launch_bounds__(256) void k_ndp_emit(const c32 *__restrict__ iq0, u
                                                   const gr80211_frame_desc *__restrict__ descs,
                                                   int n, const gr80211_frame_info *__restrict__ info,
                                                   uint8_t *__restrict__ out, int out_stride, int32_t *__restrict__ out_len,
-                                                  int32_t *__restrict__ n_pdu)
+                                                  int32_t *__restrict__ n_pdu, const SchedTotals *__restrict__ totals)
 {
     const int f = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (f >= n) return;
+    if (totals && totals->n_groups < 0) return;  // a refused batch publishes nothing, channel messages included
     const gr80211_frame_info fi = info[f];
     if (fi.status != GR80211_ST_NDP) return;
     constexpr int NBYTES = 128 * 8;
@@ -2131,10 +2132,10 @@ void launch_decode_split2(const float *llr, const gr80211_frame_info *info, cons
 }
 void launch_ndp_emit(const void *iq0, uint64_t arena_len, const gr80211_frame_desc *desc, int n,
                      const gr80211_frame_info *info, uint8_t *out, int out_stride, int32_t *out_len, int32_t *n_pdu,
-                     hipStream_t s)
+                     const SchedTotals *totals, hipStream_t s)
 {
     hipLaunchKernelGGL(k_ndp_emit, dim3((n + 3) / 4), dim3(256), 0, s, (const c32 *)iq0, arena_len, desc, n, info, out, out_stride,
-                       out_len, n_pdu);
+                       out_len, n_pdu, totals);
 }
 void launch_pre_gather(const int32_t *path, int n, const gr80211_frame_info *info_in, const void *chan1_in,
                        const void *chan2_in, gr80211_frame_info *info_out, void *chan1_out, void *chan2_out, hipStream_t s)

@@ -405,7 +405,9 @@ int gr80211_copy_d2d(gr80211_ctx *ctx, void *d_dst, const void *d_src, size_t by
  * and stay untouched until the copy has run.
  *   gr80211_pull_h2d       host-to-device copy done by a kernel that reads page-locked host memory over the link (memory
  *                          from gr80211_host_alloc; fastest with both ends 16-byte aligned, any alignment works): the
- *                          host pays one kernel launch whatever the size, and pieces below about 1 MB move faster than
+ *                          host pays one kernel launch whatever the size, all pull copies of a context go to ONE stream
+ *                          (the stream of its first pull; another stream is refused with GR80211_ERR_ARG: the copies
+ *                          share one completion counter and flag; use one context per upload stream), and pieces below about 1 MB move faster than
  *                          by the runtime's copy engine (256 KiB: 32 GB/s against 18).  Returns the copy's number
  *                          (>= 1) or a negative code.
  *   gr80211_pull_done      1 if copy `number` has read all of its source (the source may be overwritten), 0 if not;

@@ -766,6 +766,28 @@ def test_resume_after_signal_batch_equals_rx_batch(pkg, oracle):
         small.sync()
         assert small.lib.gr80211_last_batch_refused(small.h) == 0 and torch.equal(out_len, want["out_len"])
         small.close()
+        # a context whose buffers are large already (`ctx` has run the whole batch above) and records that understate
+        # the NUMBER of frames the decoder admits (most marked as dropped): every buffer has room, so only the group
+        # count the decoder was launched for can tell -- the scheduler arrives at more groups and refuses the batch
+        ctx.signal_batch(d0, None, desc, n)
+        few = info_all.copy()
+        few["status"][info_all["cr"] != info_all["cr"][sel[0]]] = 1   # frames of one code rate only: one group, not four
+        out_len.fill_(-1)
+        ctx.rx_resume(d0, None, dsel, sel, few, out, out_len, n_pdu)
+        ctx.sync()
+        assert ctx.lib.gr80211_last_batch_refused(ctx.h) == 1
+        assert int(out_len.abs().sum().item()) == 0 and int(n_pdu.abs().sum().item()) == 0
+        # ... and none at all: the host skips the decoder, the device still says what it found
+        none = info_all.copy()
+        none["status"][:] = 1
+        ctx.signal_batch(d0, None, desc, n)
+        ctx.rx_resume(d0, None, dsel, sel, none, out, out_len, n_pdu)
+        ctx.sync()
+        assert ctx.lib.gr80211_last_batch_refused(ctx.h) == 1
+        ctx.signal_batch(d0, None, desc, n)
+        ctx.rx_resume(d0, None, dsel, sel, info_all, out, out_len, n_pdu)
+        ctx.sync()
+        assert ctx.lib.gr80211_last_batch_refused(ctx.h) == 0 and torch.equal(out_len, want["out_len"])
     finally:
         ctx.close()
         ref.close()

@@ -120,3 +120,40 @@ def test_no_alloc_entry_refuses_what_does_not_fit(pkg):
             ctx.decode_batch_noalloc(llr, bad, 4, *bufs)
     finally:
         ctx.close()
+
+
+def test_no_alloc_entry_leaves_device_memory_as_it_is(pkg):
+    """The property the entry point is named for: repeated calls on a warmed context, of growing and shrinking
+    batches, leave the free device memory where it was (hipMemGetInfo through torch; gr80211_decode_batch on the
+    same inputs, which grows its work buffers, is the contrast that shows the probe sees allocations)."""
+    import torch
+    tx = pkg.txgen
+    rng = np.random.default_rng(79)
+    batches = [_batch(tx, rng, [(2, 2, 1400, 8, 1.0)] * k) for k in (16, 200, 60, 440)]
+    packed = [(_pack(pkg.rx, b), len(b)) for b in batches]
+    llrs = [torch.from_numpy(p[0][1]).cuda() for p in packed]
+    cap = 440
+    bufs = (torch.zeros((cap, 1600), dtype=torch.uint8, device="cuda"), torch.zeros(cap, dtype=torch.int32, device="cuda"),
+            torch.zeros(cap, dtype=torch.int32, device="cuda"))
+    ctx = pkg.RxContext(0)
+    try:
+        (desc, _), n = packed[0]
+        ctx.decode_batch_noalloc(llrs[0], desc, n, *bufs)      # first call: page-locked staging and events exist now
+        ctx.sync()
+        torch.cuda.synchronize()
+        free0 = torch.cuda.mem_get_info()[0]
+        for _ in range(3):
+            for ((desc, _), n), llr in zip(packed, llrs):
+                ctx.decode_batch_noalloc(llr, desc, n, *bufs)
+                ctx.sync()
+                assert int(bufs[2][:n].sum().item()) == n
+                assert torch.cuda.mem_get_info()[0] == free0
+        # the allocating entry point on the largest batch does move the figure (its survivor arena alone is 43 MB)
+        (desc, _), n = packed[3]
+        res = ctx.decode_batch(llrs[3], desc, n, out_stride=1600)
+        ctx.sync()
+        del res
+        torch.cuda.empty_cache()
+        assert torch.cuda.mem_get_info()[0] < free0
+    finally:
+        ctx.close()
