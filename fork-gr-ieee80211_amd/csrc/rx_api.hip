@@ -88,7 +88,10 @@ struct gr80211_ctx {
     bool profiling = false;
     bool split_decode = false;  // GR80211_SPLIT_DECODE=1: forward pass and traceback as two kernels
     int group_waves = -1;       // GR80211_GROUP_WAVES=1|2|4: wavefronts per decoder group (-1: by batch size); 10: one, in the
-                                // form batches of more than 1024 groups take (k_decode_lean) whatever the size
+                                // form batches of more than 1024 groups take (k_decode_lean) whatever the size; 64: one
+                                // wavefront per frame (lane = trellis state)
+    int lane_state_max = 14000;  // batches of at most this many frames take the one-wavefront-per-frame form
+                                // (GR80211_LANE_STATE_MAX; 0 switches the form off)
     hipEvent_t ev[7] = {};
     float ms[6] = {};
 };
@@ -309,8 +312,16 @@ int finish_decode_stages(gr80211_ctx *c, hipStream_t s, int n, bool from_iq, con
             // (tools/width_sweep.sh: 500 groups 5.6 / 6.5 / 7.7 ms by four / two / one waves, 625 groups 7.8 / 6.8 / 7.9,
             // 1024 groups 11.4 / 8.0 / 8.9, 1125 groups 13.0 / 11.8 / 10.6)
             if (gw == 10) gw = 1;  // one wave per group in the form large batches take
-            if (gw != 1 && gw != 2 && gw != 4) gw = tot.n_groups <= 512 ? 4 : tot.n_groups <= 1024 ? 2 : 1;
-            if (gw == 2 && !c->split_decode) {
+            // few frames: one wave per frame, one state per lane (the frame count is exact when it comes from the
+            // scheduler, an upper bound when the batch was launched without waiting for it)
+            if (gw != 1 && gw != 2 && gw != 4 && gw != 64)
+                gw = tot.n_valid <= c->lane_state_max ? 64 : tot.n_groups <= 512 ? 4 : tot.n_groups <= 1024 ? 2 : 1;
+            if (gw == 64) {
+                launch_decode_lane_state(llr, info, (const int32_t *)c->slot_frame.p, (const GroupInfo *)c->groups.p, tot.n_groups,
+                                         (uint32_t *)c->dec.p, (uint32_t *)c->bitsw.p, d_out, out_stride, d_out_len, d_n_pdu, d_bits,
+                                         bits_stride, c->ampdu_strict, dt, s);
+                mark(c, 4, s);
+            } else if (gw == 2 && !c->split_decode) {
                 launch_decode_split2(llr, info, (const int32_t *)c->slot_frame.p, (const GroupInfo *)c->groups.p, tot.n_groups,
                                      (uint32_t *)c->dec.p, (uint32_t *)c->bitsw.p, d_out, out_stride, d_out_len, d_n_pdu, d_bits,
                                      bits_stride, c->ampdu_strict, dt, s);
@@ -669,6 +680,7 @@ int gr80211_create(gr80211_ctx **out, int device)
     c->device = device;
     if (const char *e = getenv("GR80211_SPLIT_DECODE")) c->split_decode = e[0] == '1';
     if (const char *e = getenv("GR80211_GROUP_WAVES")) c->group_waves = atoi(e);
+    if (const char *e = getenv("GR80211_LANE_STATE_MAX")) c->lane_state_max = atoi(e);
     {
         std::lock_guard<std::mutex> lk(g_upload_mutex);
         if (!g_uploaded[device]) {

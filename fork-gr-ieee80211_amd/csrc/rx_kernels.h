@@ -88,6 +88,12 @@ int read_timeline(unsigned long long *dst, int n_groups);
 void launch_decode_split2(const float *llr, const gr80211_frame_info *info, const int32_t *slot_frame, const GroupInfo *groups,
                           int n_groups, uint32_t *dec, uint32_t *bitsw, uint8_t *out, int out_stride, int32_t *out_len,
                           int32_t *n_pdu, uint8_t *bits_out, int bits_stride, int strict, const SchedTotals *totals, hipStream_t s);
+// One frame per wavefront, one trellis state per lane (lane_state.hip): forward pass, walk back and packet assembly
+// in one kernel, for batches of so few frames that the forms above leave most of the chip idle.  Uses the same
+// group layout: a frame's survivor words and decoded bits take its 64th of its group's areas.
+void launch_decode_lane_state(const float *llr, const gr80211_frame_info *info, const int32_t *slot_frame, const GroupInfo *groups,
+                              int n_groups, uint32_t *dec, uint32_t *bitsw, uint8_t *out, int out_stride, int32_t *out_len,
+                              int32_t *n_pdu, uint8_t *bits_out, int bits_stride, int strict, const SchedTotals *totals, hipStream_t s);
 void launch_ndp_emit(const void *iq0, uint64_t arena_len, const gr80211_frame_desc *desc, int n,
                      const gr80211_frame_info *info, uint8_t *out, int out_stride, int32_t *out_len, int32_t *n_pdu,
                      const SchedTotals *totals, hipStream_t s);

@@ -180,14 +180,14 @@ def test_linearity_property_full_size(pkg, rxctx, oracle):
 
 @pytest.fixture(scope="module")
 def ctx_by_waves(pkg):
-    """Contexts pinned to 1, 2 and 4 wavefronts per decoder group, and to the one-wave form of batches beyond 1024
-    groups (10) (by default the library chooses by batch size, so the small batches of these tests would all take the
-    four-wave path)."""
+    """Contexts pinned to 1, 2 and 4 wavefronts per decoder group, to the one-wave form of batches beyond 1024
+    groups (10) and to one wavefront per frame with a trellis state per lane (64) (by default the library chooses by
+    batch size, so the small batches of these tests would all take the last one)."""
     import os
     made = {}
     old = os.environ.get("GR80211_GROUP_WAVES")
     try:
-        for w in (1, 2, 4, 10):
+        for w in (1, 2, 4, 10, 64):
             os.environ["GR80211_GROUP_WAVES"] = str(w)
             made[w] = pkg.RxContext(0)
     finally:
@@ -200,7 +200,7 @@ def ctx_by_waves(pkg):
         c.close()
 
 
-@pytest.mark.parametrize("waves", [1, 2, 4, 10])
+@pytest.mark.parametrize("waves", [1, 2, 4, 10, 64])
 def test_each_group_width_against_oracle(pkg, ctx_by_waves, oracle, waves):
     """Ragged lengths, all four code rates, integer LLRs with many ties: every way of spreading a group over
     wavefronts gives the oracle's bits and PDUs."""
@@ -241,7 +241,7 @@ def test_group_widths_agree_bit_for_bit(pkg, ctx_by_waves):
         got[w] = (r["out"].cpu().numpy(), r["out_len"].cpu().numpy(), r["n_pdu"].cpu().numpy(), r["bits"].cpu().numpy())
     assert 0 < int(got[1][2].sum()) < n   # some frames fail the FCS, some pass
     valid = np.arange(768)[None, :] < got[1][1][:, None]   # the slots are uninitialised beyond out_len
-    for w in (2, 4):
+    for w in (2, 4, 10, 64):
         assert np.array_equal(got[1][1], got[w][1]) and np.array_equal(got[1][2], got[w][2]), w
         # decoded bits up to each frame's own trellis length (what lies beyond depends on the other frames that
         # happen to share its group)
@@ -271,7 +271,7 @@ def test_reference_bit_vector_decodes_to_reference_packet(pkg, ctx_by_waves):
         desc[i] = (i * len(llr), len(llr), 1, 94, 0, 0, 0, 8 * 94 + 22, 0)
     d_llr = torch.from_numpy(np.tile(llr, n)).cuda()
     want = bytes([1, 94, 0]) + ref_fixture_mpdu() + bytes([0])
-    for waves in (1, 4):
+    for waves in (1, 4, 64):
         c = ctx_by_waves[waves]
         r = c.decode_batch(d_llr, desc, n)
         c.sync()
