@@ -576,6 +576,7 @@ def main():
     ap.add_argument("--in-flight", type=int, default=2,
                     help="also time the same steps with this many batches in flight (one context, stream and host "
                          "thread each; N = 1 only; 1 = skip)")
+    ap.add_argument("--latency", type=int, default=1, help="also time small batches one at a time (0 = skip)")
     ap.add_argument("--force-collective", action="store_true",
                     help="N = 1: run the exchange step all the same (process group of one rank, the gather of the MPDUs on "
                          "device tensors, its stream ordering and the check of what arrived): the N > 1 code path on one GPU")
@@ -965,6 +966,55 @@ def main():
         res["host_buffers"] = {"value": samples_per_step / world / dth / 1e6, "unit": "Msamples/s", "ms_per_step": dth * 1e3,
                                "note": "IQ arena H2D + step + PDU slots D2H over PCIe, pinned host memory; not the headline"}
         del h_in, h_out, h_len
+
+    # ---- small batches one at a time: what a receiver that gets n frames and wants them back pays (call + wait)
+    if rank == 0 and not collective and len(parts) == 1 and args.latency:
+        import ctypes as C
+        lat = []
+        lctx = pkg.RxContext(local)
+        for nl in (1, 64, 1000, 4000, 16000):
+            if nl > n:
+                continue
+            d_n = parts[0][2][: nl * 32]
+            o_l, ol_l, np_l = out[:nl], out_len[:nl], n_pdu[:nl]
+            ts = []
+            for _ in range(9):
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                lctx.rx_batch_into(arena, arena1, d_n, nl, o_l, ol_l, np_l)
+                lctx.sync()
+                ts.append((time.perf_counter() - t1) * 1e3)
+            rec = {"frames": nl, "rx_batch_ms": float(np.median(ts[2:])), "fcs_ok": int(np_l.sum().item())}
+            # the decoder alone on the same frames' soft bits (gr80211_demod_batch leaves them in the context)
+            info_t = torch.empty(nl * pkg.rx.FRAME_INFO_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+            llr_ptr, nfl = C.c_void_p(), C.c_uint64(0)
+            rcq = lctx.lib.gr80211_demod_batch(lctx.h, arena.data_ptr(), arena1.data_ptr() if arena1 is not None else None,
+                                               arena.numel(), d_n.data_ptr(), nl, 1, info_t.data_ptr(), C.byref(llr_ptr),
+                                               C.byref(nfl), None)
+            lctx.sync()
+            if rcq == 0 and nfl.value:
+                fi = info_t.cpu().numpy().view(pkg.rx.FRAME_INFO_DTYPE)
+                dd = np.zeros(nl, dtype=pkg.rx.DEC_DESC_DTYPE)
+                for k_ in ("llr_off", "format", "len", "cr", "mcs", "ampdu", "trellis"):
+                    dd[k_] = fi[k_]
+                dd["n_llr"] = fi["total"]
+                dctx = ctx  # another context: the soft bits belong to lctx
+                ts = []
+                for _ in range(9):
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    rcq = dctx.lib.gr80211_decode_batch(dctx.h, llr_ptr, nfl.value, dd.ctypes.data, nl, 0, o_l.data_ptr(),
+                                                        o_l.shape[1], ol_l.data_ptr(), np_l.data_ptr(), None, 0, None)
+                    dctx.lib.gr80211_sync(dctx.h, None)
+                    ts.append((time.perf_counter() - t1) * 1e3)
+                rec["decode_batch_ms"] = float(np.median(ts[2:]))
+                rec["decode_fcs_ok"] = int(np_l.sum().item())
+            lat.append(rec)
+        lctx.close()
+        res["latency"] = {"batches": lat,
+                          "note": "first n frames of the corpus, one batch at a time on an idle GPU, median of 7: call + "
+                                  "wait for the stream; rx_batch from IQ (descriptors on the device: one wait for the "
+                                  "scheduler inside the call), decode_batch from resident soft bits (host descriptors)"}
 
     # ---- BASELINE.json configs[4] beside the headline: the capture corpus, sharded like everything else (every rank
     # its 125 000 replicas), MPDUs gathered on rank 0 packed to their lengths

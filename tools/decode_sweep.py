@@ -53,7 +53,7 @@ def main():
         frames.append(f)
     t0 = time.time()
     ok = {}
-    for waves in (1, 2, 4, 10):  # 10: one wave per group in the form of batches beyond 1024 groups
+    for waves in (1, 2, 4, 10, 64):  # 10: one wave per group in the form of batches beyond 1024 groups; 64: one wave per frame
         os.environ["GR80211_GROUP_WAVES"] = str(waves)
         ctx = pkg.RxContext(0)
         ok[str(waves)] = run_and_compare(pkg, ctx, O, frames)
