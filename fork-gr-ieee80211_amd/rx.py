@@ -399,6 +399,31 @@ class RxContext:
         info_h = info.cpu().numpy().view(FRAME_INFO_DTYPE)
         return info_h, llr[: int(nfl.value)]
 
+    def demod_batch_device(self, iq0, iq1, desc, n_frames):
+        """demod_batch without the copy of the whole soft-bit arena: returns (info ndarray, read) where
+        read(off, n) fetches n soft bits from float offset `off` of the arena the context holds until its next call."""
+        t = self.torch
+        info = t.empty(n_frames * FRAME_INFO_DTYPE.itemsize, dtype=t.uint8, device=self.dev)
+        dp, flags, keep = self._desc_arg(desc)
+        llr_ptr = C.c_void_p()
+        nfl = C.c_uint64(0)
+        rc = self.lib.gr80211_demod_batch(
+            self.h, C.c_void_p(iq0.data_ptr()), C.c_void_p(iq1.data_ptr()) if iq1 is not None else None,
+            iq0.numel(), dp, n_frames, flags, C.c_void_p(info.data_ptr()), C.byref(llr_ptr), C.byref(nfl),
+            self._stream())
+        self._check(rc, "gr80211_demod_batch")
+        self.sync()
+        total = int(nfl.value)
+
+        def read(off, n):
+            assert 0 <= off and off + n <= total
+            a = np.zeros(max(n, 1), dtype=np.float32)
+            if n:
+                self._check(self.lib.gr80211_copy_d2h(self.h, C.c_void_p(a.ctypes.data), C.c_void_p(llr_ptr.value + 4 * off),
+                                                      4 * n, self._stream()), "copy_d2h")
+            return a[:n]
+        return info.cpu().numpy().view(FRAME_INFO_DTYPE), read
+
     def signal_emit(self, iq0, iq1, desc, n_frames, out_off, out_items):
         """`signal` alone: (info ndarray, chan [n, 64] complex64 ndarray, out0, out1 CUDA tensors).  out_off: item
         offset of every frame in the output (host array of uint64)."""

@@ -46,15 +46,23 @@ def test_configured_batch_round_trip(pkg, rxctx, oracle, workload, n_oracle):
     assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
     assert torch.equal(outs[0][0][ok], outs[1][0][ok])
     # the oracle on a sample spread over the batch (includes frames that fail, if any are in the sample)
+    # ... and the soft bits of the same frames out of one gr80211_demod_batch over the whole batch: the tolerance the
+    # path states for them (1e-4 relative, tests/util.py), at the configured batch size
+    from util import LLR_ATOL, LLR_RTOL
     pick = np.unique(np.linspace(0, n - 1, n_oracle).astype(np.int64))
     lens = out_len.cpu().numpy()
+    info, read_llr = rxctx.demod_batch_device(a0, a1, desc, n)
     for i in pick:
         s, e = int(sync[i]) - 176, int(sync[i]) + int(navail[i])
         h0 = a0[s:e].cpu().numpy()
         h1 = a1[s:e].cpu().numpy() if a1 is not None else None
-        ref = oracle.rx_frame(h0, h1, 176, 0.0, want_llr=False)
+        ref = oracle.rx_frame(h0, h1, 176, 0.0, want_llr=True)
         got = bytes(out[i, : lens[i]].cpu().numpy())
         assert got == ref["blob"], (workload, int(i))
+        assert int(info["status"][i]) == ref["status"] == 0 and int(info["total"][i]) == len(ref["llr"]), (workload, int(i))
+        g = read_llr(int(info["llr_off"][i]), int(info["total"][i]))
+        assert len(g) > 10000
+        assert np.all(np.abs(g - ref["llr"]) <= LLR_ATOL + LLR_RTOL * np.abs(ref["llr"])), (workload, int(i))
 
 
 @pytest.mark.parametrize("two_ant,n_frames", [(False, 125000), (False, 52000), (True, 20000)])

@@ -7,12 +7,12 @@
 #define KERNEL(NAME, ASM)                                                                       \
     __global__ void NAME(float *out, long long *cyc, int iters)                                 \
     {                                                                                           \
-        float a = threadIdx.x, b = 1.5f, c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0, c6 = 0, c7 = 0; \
+        float a = threadIdx.x, b = 1.5f, d = 0.25f + threadIdx.x, c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0, c6 = 0, c7 = 0; \
         unsigned u = threadIdx.x;                                                               \
         long long t0 = __builtin_amdgcn_s_memtime();                                            \
         for (int i = 0; i < iters; i++) {                                                       \
             asm volatile(REP8(ASM) : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "+v"(c4), "+v"(c5), "+v"(c6), "+v"(c7) \
-                         : "v"(a), "v"(b), "v"(u) : "vcc", "s20", "s21", "s22", "s23");                                     \
+                         : "v"(a), "v"(b), "v"(u), "v"(d) : "vcc", "s20", "s21", "s22", "s23");                                     \
         }                                                                                       \
         long long t1 = __builtin_amdgcn_s_memtime();                                            \
         out[blockIdx.x * blockDim.x + threadIdx.x] = c0 + c1 + c2 + c3 + c4 + c5 + c6 + c7;     \
@@ -52,6 +52,27 @@ KERNEL(k_addu, L8("v_add_u32_e32", "%10, %10"))
 KERNEL(k_max3, L8("v_max3_f32", "%8, %9, %8"))
 KERNEL(k_sub64, L8("v_sub_f32_e64", "%8, %9"))
 
+// Operand patterns of the two instructions whose rate disagrees with the plain add: three distinct sources, the
+// two-operand multiply-accumulate form, destination among the sources, VOP3 encoding.
+KERNEL(k_fma_3src, L8("v_fma_f32", "%8, %9, %11"))
+KERNEL(k_fmac, L8("v_fmac_f32_e32", "%8, %9"))
+KERNEL(k_mul, L8("v_mul_f32_e32", "%8, %9"))
+KERNEL(k_mac_dpp, L8("v_mul_f32_e32", "%8, %8"))
+KERNEL(k_max_e64, L8("v_max_f32_e64", "%8, %9"))
+KERNEL(k_max_same, L8("v_max_f32_e32", "%8, %8"))
+#define L8S(OP, SRC) OP " %0, %0, " SRC "\n" OP " %1, %1, " SRC "\n" OP " %2, %2, " SRC "\n" OP " %3, %3, " SRC "\n" \
+                     OP " %4, %4, " SRC "\n" OP " %5, %5, " SRC "\n" OP " %6, %6, " SRC "\n" OP " %7, %7, " SRC "\n"
+KERNEL(k_max_inplace, L8S("v_max_f32_e32", "%8"))
+KERNEL(k_add_inplace, L8S("v_add_f32_e32", "%8"))
+KERNEL(k_writelane, L8N("v_writelane_b32", "%0, s20, 3"))
+KERNEL(k_mov_dpp, L8("v_mov_b32_dpp", "%8 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"))
+KERNEL(k_add_dpp, L8("v_add_f32_dpp", "%8, %9 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"))
+KERNEL(k_mov_dpp_ror, L8("v_mov_b32_dpp", "%8 row_ror:8 row_mask:0xf bank_mask:0xf"))
+KERNEL(k_swap32, "v_permlane32_swap_b32_e32 %0, %1\nv_permlane32_swap_b32_e32 %2, %3\nv_permlane32_swap_b32_e32 %4, %5\nv_permlane32_swap_b32_e32 %6, %7\n"
+                 "v_permlane32_swap_b32_e32 %0, %1\nv_permlane32_swap_b32_e32 %2, %3\nv_permlane32_swap_b32_e32 %4, %5\nv_permlane32_swap_b32_e32 %6, %7\n")
+KERNEL(k_swap16, "v_permlane16_swap_b32_e32 %0, %1\nv_permlane16_swap_b32_e32 %2, %3\nv_permlane16_swap_b32_e32 %4, %5\nv_permlane16_swap_b32_e32 %6, %7\n"
+                 "v_permlane16_swap_b32_e32 %0, %1\nv_permlane16_swap_b32_e32 %2, %3\nv_permlane16_swap_b32_e32 %4, %5\nv_permlane16_swap_b32_e32 %6, %7\n")
+
 typedef void (*kfn)(float *, long long *, int);
 void run(const char *name, kfn f)
 {
@@ -85,5 +106,12 @@ int main()
     run("cndmask64", k_cndmask64); run("cmp_e32", k_cmp32); run("cmp_e64", k_cmp64); run("addc_e32", k_addc32);
     run("addc_e64", k_addc64); run("ashr", k_ashr); run("min_f32", k_min); run("max_u32", k_maxu); run("max_i32", k_maxi);
     run("or", k_or); run("lshlrev", k_lshlrev);
+    printf("-- operand patterns\n");
+    run("fma a,b,a", k_fma); run("fma a,b,d", k_fma_3src); run("fmac a,b", k_fmac); run("mul a,b", k_mul); run("mul a,a", k_mac_dpp);
+    run("max a,b e32", k_max); run("max a,b e64", k_max_e64); run("max a,a", k_max_same); run("max c,c,a", k_max_inplace);
+    run("add c,c,a", k_add_inplace);
+    printf("-- lane exchange (the lane = state decoder)\n");
+    run("writelane", k_writelane); run("mov_dpp quad", k_mov_dpp); run("add_dpp quad", k_add_dpp); run("mov_dpp ror8", k_mov_dpp_ror);
+    run("swap32", k_swap32); run("swap16", k_swap16);
     return 0;
 }
