@@ -456,10 +456,12 @@ class Rotation:
     """The timed steps of one corpus: contexts, their streams, rotating output tensors and the MPDU gather."""
 
     def __init__(self, torch, dist, pkg, shard, local, dev, parts, n, out_stride, pipe, collective, compact, first_ctx,
-                 side_copy=False):
+                 side_copy=False, pool=0):
         self.torch, self.dist, self.parts, self.n, self.pipe = torch, dist, parts, n, pipe
         self.depth = max(pipe, 2 if collective else 1)
         self.ctxs = [first_ctx] + [pkg.RxContext(local) for _ in range(pipe - 1)]
+        for c in self.ctxs:
+            c.use_work_pool(pool)
         self.outs = [(torch.zeros((n, out_stride), dtype=torch.uint8, device=dev),
                       torch.zeros(n, dtype=torch.int32, device=dev),
                       torch.zeros(n, dtype=torch.int32, device=dev)) for _ in range(self.depth)]
@@ -576,6 +578,9 @@ def main():
     ap.add_argument("--in-flight", type=int, default=2,
                     help="also time the same steps with this many batches in flight (one context, stream and host "
                          "thread each; N = 1 only; 1 = skip)")
+    ap.add_argument("--pool", type=int, default=-1,
+                    help="work sets (soft bits, survivor words, decoded bits) the rotating contexts share "
+                         "(gr80211_use_work_pool); 0 = every context its own; -1 = three when more than three contexts rotate")
     ap.add_argument("--latency", type=int, default=1, help="also time small batches one at a time (0 = skip)")
     ap.add_argument("--force-collective", action="store_true",
                     help="N = 1: run the exchange step all the same (process group of one rank, the gather of the MPDUs on "
@@ -657,10 +662,15 @@ def main():
     queues = int(os.environ.get("GPU_MAX_HW_QUEUES", "4") or 4)
     pipe = args.pipeline if args.pipeline > 0 else (6 if queues >= 8 else 3 if not collective else 2)
     compact = args.gather == "compact" or (args.gather == "auto" and args.workload in (MIXED, CAPTURE))
+    pool = args.pool if args.pool >= 0 else (3 if pipe > 3 else 0)
     rot = Rotation(torch, dist, pkg, shard, local, dev, parts, n, out_stride, pipe, collective, compact, ctx,
-                   side_copy=args.side_copy and not collective)
+                   side_copy=args.side_copy and not collective, pool=pool)
     out, out_len, n_pdu = rot.outs[0]
     dt = max_over_ranks(rot.timed(args.steps, args.warmup, collective))
+    free_b, total_b = torch.cuda.mem_get_info(dev)
+    mem_after_timed = (total_b - free_b) / 1e9
+    wm = [c.work_memory() for c in rot.ctxs]
+    work_gb = (sum(w[0] for w in wm) + wm[0][1]) / 1e9
 
     # ---- with the exchange: the same steps without it, to show what the gather costs (not the headline)
     value_local = None
@@ -811,7 +821,7 @@ def main():
                    "parallelism": ("frames sharded per rank, gather of MPDUs to rank 0 over %s" %
                                    ("RCCL" if backend == "nccl" else backend + " (host-staged rehearsal, ranks share GPUs)"))
                    if collective else "single GPU",
-                   "batches_in_flight": pipe, "hw_queues": queues},
+                   "batches_in_flight": pipe, "work_sets_shared": pool, "hw_queues": queues},
         "psdu": {"frames": n, "fcs_ok": n_ok, "bit_exact_vs_tx": bitexact, "fcs_ok_but_wrong": wrong},
         "kernel_ms": timing,
     }
@@ -820,6 +830,13 @@ def main():
         res["kernel_ms_note"] = ("kernel_ms: separate steps on one context, nothing beside them (HIP events); ms_per_step: "
                                  "steps rotating over %d contexts whose kernels overlap, so a kernel's time alone can exceed "
                                  "a step's share of the rotation" % pipe)
+    res["device_memory"] = {"allocated_GB_peak_torch": torch.cuda.max_memory_allocated(dev) / 1e9,
+                            "in_use_GB_after_timed_steps": mem_after_timed,
+                            "library_work_buffers_GB": work_gb, "work_sets_in_pool": wm[0][2],
+                            "note": "in_use: total minus free device memory (hipMemGetInfo) right after the timed steps: corpus, "
+                                    "output slots, what torch's allocator keeps cached and the library's work buffers; "
+                                    "library_work_buffers: soft bits, survivor words and decoded bits of the rotating "
+                                    "contexts and of the pool they share (gr80211_work_memory)"}
     if serial_ms is not None:
         res["one_batch_at_a_time"] = {"ms_per_step": serial_ms, "value": samples_per_step / serial_ms / 1e3,
                                       "unit": "Msamples/s",
@@ -1026,7 +1043,8 @@ def main():
         ncap = DEFAULT_FRAMES[CAPTURE]
         cc = build_corpus_capture(torch, ctx, ncap, dev)
         stride_c = ((cc["blob_len"] + 4 + 63) // 64) * 64
-        rc = Rotation(torch, dist, pkg, shard, local, dev, cc["parts"], ncap, stride_c, pipe, collective, args.gather != "fixed", ctx)
+        rc = Rotation(torch, dist, pkg, shard, local, dev, cc["parts"], ncap, stride_c, pipe, collective, args.gather != "fixed", ctx,
+                      pool=pool)
         steps_c = max(4, args.steps // 2)
         dtc = max_over_ranks(rc.timed(steps_c, args.warmup, collective))
         o_c, ol_c, np_c = rc.outs[0]

@@ -5,6 +5,7 @@
 #include <atomic>
 #include <mutex>
 #include <utility>
+#include <vector>
 #include <string>
 
 #include "detect_kernels.h"
@@ -35,6 +36,11 @@ static __device__ __align__(256) unsigned char scratch[NA_SCRATCH_BYTES];
 void *g_scratch[64] = {};
 
 }  // namespace
+
+struct PoolLeaseBase {
+    virtual void engage() = 0;  // from here on the call's kernels touch the set: wait (on the device) for its last user
+    virtual ~PoolLeaseBase() = default;
+};
 
 struct gr80211_ctx {
     int device = 0;
@@ -83,6 +89,8 @@ struct gr80211_ctx {
     static constexpr int N_MARK = 256;
     hipEvent_t mark_ev[N_MARK] = {};        // gr80211_marker_*: created on first use
     long long mark_next = 0;
+    struct PoolLeaseBase *lease = nullptr;  // the work set a batch call in progress holds
+    int pool_sets = 0;     // > 0: soft bits, survivor words and decoded bits come from the device's pool of work sets
     int ampdu_strict = 0;  // de-aggregate A-MPDUs by the standard's rules instead of the reference's
     uint32_t mu_pos = 0;  // MU group position written into the descriptors frame detection makes
     bool profiling = false;
@@ -131,8 +139,9 @@ int ensure(gr80211_ctx *c, Buf &b, size_t bytes)
 {
     if (bytes <= b.cap) return GR80211_OK;
     if (b.fixed) return fail(c, GR80211_ERR_NOMEM, "the batch needs more work memory than the fixed scratch array holds");
-    // grow with headroom so steady-state batches of similar size never reallocate
-    size_t want = bytes + bytes / 8 + 4096;
+    // grow with headroom so steady-state batches of similar size never reallocate (an eighth; a thirty-second for
+    // buffers of a gigabyte and more, where an eighth is gigabytes)
+    size_t want = bytes + (bytes >= ((size_t)1 << 30) ? bytes / 32 : bytes / 8) + 4096;
     if (b.p) {
         hipError_t e = hipFree(b.p);
         b.p = nullptr;
@@ -156,6 +165,127 @@ void release(Buf &b)
 }
 
 hipStream_t pick(gr80211_ctx *c, void *stream) { return stream ? (hipStream_t)stream : c->stream; }
+
+// ---- work sets shared by the contexts of a device ---------------------------------------------------------------
+// The three large work buffers of a batch (soft bits, survivor words, decoded bits) are live from the demodulator to
+// the end of the decoder only.  Contexts that rotate over batches (one stream each, so that kernels of neighbouring
+// batches overlap) therefore need fewer sets than there are contexts: a context that has joined the pool takes a set
+// for the length of one batch call and hands it back with an event recorded behind the batch's last kernel; the next
+// taker's stream waits for that event (on the device: the host never blocks).
+struct WorkSet {
+    Buf llr, dec, bitsw;
+    hipEvent_t ev = nullptr;   // end of the last batch that used the set
+    bool pending = false;      // ev has been recorded and may not have completed
+    bool busy = false;         // held by a batch call that is still queuing its kernels (another host thread)
+    uint64_t released = 0;     // order of hand-backs: the set handed back longest ago is taken first
+};
+struct DevicePool {
+    std::vector<WorkSet *> sets;
+    int users = 0;             // contexts of this device that have joined
+    int max_sets = 0;
+    uint64_t clock = 0;
+};
+std::mutex g_pool_mutex;
+DevicePool g_pool[64];
+
+// A batch call's hold on a work set: the set's buffers stand in for the context's own for the length of the call.
+struct PoolLease : PoolLeaseBase {
+    gr80211_ctx *c;
+    WorkSet *ws = nullptr;
+    hipStream_t s;
+    bool must_wait = false;  // the set's last batch may still be running
+    Buf own_llr, own_dec, own_bitsw;
+    PoolLease(gr80211_ctx *cc, hipStream_t stream);
+    ~PoolLease() override;
+    void engage() override;
+    PoolLease(const PoolLease &) = delete;
+    PoolLease &operator=(const PoolLease &) = delete;
+};
+
+
+PoolLease::PoolLease(gr80211_ctx *cc, hipStream_t stream) : c(cc), s(stream)
+{
+    if (c->pool_sets <= 0) return;
+    std::lock_guard<std::mutex> lk(g_pool_mutex);
+    DevicePool &dp = g_pool[c->device];
+    WorkSet *done = nullptr, *oldest = nullptr;
+    for (WorkSet *w : dp.sets) {
+        if (w->busy) continue;
+        if (w->pending && hipEventQuery(w->ev) == hipSuccess) w->pending = false;
+        if (!w->pending) {
+            if (!done || w->released < done->released) done = w;
+        } else if (!oldest || w->released < oldest->released) {
+            oldest = w;
+        }
+    }
+    (void)hipGetLastError();  // hipErrorNotReady from the queries above is not an error
+    if (done) {
+        ws = done;
+    } else if ((int)dp.sets.size() < dp.max_sets) {
+        WorkSet *w = new WorkSet();
+        if (hipEventCreateWithFlags(&w->ev, hipEventDisableTiming) != hipSuccess) {
+            delete w;
+            return;  // the context's own buffers serve
+        }
+        dp.sets.push_back(w);
+        ws = w;
+    } else if (oldest) {
+        // its last batch is still running: this batch's kernels that touch the set queue up behind it on the device
+        // (engage), the ones before them -- preamble, scheduler -- do not
+        must_wait = true;
+        ws = oldest;
+    } else {
+        return;  // every set is held by a call in progress on another thread: the context's own buffers serve
+    }
+    ws->busy = true;
+    own_llr = c->llr, own_dec = c->dec, own_bitsw = c->bitsw;
+    c->llr = ws->llr, c->dec = ws->dec, c->bitsw = ws->bitsw;
+    c->lease = this;
+}
+
+void PoolLease::engage()
+{
+    if (!ws || !must_wait) return;
+    must_wait = false;
+    if (hipStreamWaitEvent(s, ws->ev, 0) != hipSuccess) (void)hipEventSynchronize(ws->ev);
+}
+
+PoolLease::~PoolLease()
+{
+    if (!ws) return;
+    c->lease = nullptr;
+    // the call may have grown the buffers: the set keeps what the context holds now
+    ws->llr = c->llr, ws->dec = c->dec, ws->bitsw = c->bitsw;
+    c->llr = own_llr, c->dec = own_dec, c->bitsw = own_bitsw;
+    const bool recorded = hipEventRecord(ws->ev, s) == hipSuccess;
+    std::lock_guard<std::mutex> lk(g_pool_mutex);
+    DevicePool &dp = g_pool[c->device];
+    ws->pending = recorded;
+    if (!recorded) (void)hipStreamSynchronize(s);  // without the event the set is only safe once the stream has run dry
+    ws->busy = false;
+    ws->released = ++dp.clock;
+}
+
+// A context leaves the pool (or is destroyed): with the last user gone the sets are freed.
+void pool_leave(gr80211_ctx *c)
+{
+    if (c->pool_sets <= 0) return;
+    c->pool_sets = 0;
+    std::lock_guard<std::mutex> lk(g_pool_mutex);
+    DevicePool &dp = g_pool[c->device];
+    if (--dp.users > 0) return;
+    (void)hipDeviceSynchronize();
+    for (WorkSet *w : dp.sets) {
+        release(w->llr);
+        release(w->dec);
+        release(w->bitsw);
+        if (w->ev) (void)hipEventDestroy(w->ev);
+        delete w;
+    }
+    dp.sets.clear();
+    dp.max_sets = 0;
+    dp.users = 0;
+}
 
 // Between gr80211_rx_submit and gr80211_rx_finish the context's workspaces belong to the submitted batch: every other
 // batch entry point checks this before it stages a descriptor, grows a buffer or launches a kernel.
@@ -292,6 +422,7 @@ int finish_decode_stages(gr80211_ctx *c, hipStream_t s, int n, bool from_iq, con
     // a batch launched without waiting for the scheduler hands its kernels the scheduler's record on the device
     const SchedTotals *dt = known ? (const SchedTotals *)c->totals_d.p : nullptr;
     const float *llr = d_llr_in;
+    if (c->lease) c->lease->engage();  // the kernels from here on use the (possibly shared) work buffers
     if (from_iq) {
         if ((rc = ensure(c, c->llr, (size_t)(tot.llr_floats + 64) * sizeof(float)))) return rc;
         launch_demod(d_iq0, d_iq1, arena_len, d_desc, n, info, c->chan1.p, c->chan2.p, (float *)c->llr.p, dt, s);
@@ -681,6 +812,10 @@ int gr80211_create(gr80211_ctx **out, int device)
     if (const char *e = getenv("GR80211_SPLIT_DECODE")) c->split_decode = e[0] == '1';
     if (const char *e = getenv("GR80211_GROUP_WAVES")) c->group_waves = atoi(e);
     if (const char *e = getenv("GR80211_LANE_STATE_MAX")) c->lane_state_max = atoi(e);
+    if (const char *e = getenv("GR80211_WORK_POOL")) {
+        const int sets = atoi(e);
+        if (sets > 0) (void)gr80211_use_work_pool(c, sets);
+    }
     {
         std::lock_guard<std::mutex> lk(g_upload_mutex);
         if (!g_uploaded[device]) {
@@ -723,6 +858,7 @@ void gr80211_destroy(gr80211_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    pool_leave(c);
     for (Buf *b : {&c->desc, &c->ddesc, &c->info, &c->chan1, &c->chan2, &c->llr, &c->slot_frame, &c->groups, &c->dec,
                    &c->bitsw, &c->totals_d, &c->sched_ws, &c->blk_llr, &c->det_mask, &c->det_blk, &c->det_runs,
                    &c->det_rec, &c->det_totals_d, &c->cap_desc, &c->cap_ws, &c->tx_desc, &c->sig_desc, &c->chanl, &c->out_off,
@@ -769,6 +905,7 @@ int gr80211_rx_batch(gr80211_ctx *c, const void *d_iq0, const void *d_iq1, uint6
     if (n == 0) return GR80211_OK;
     HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t s = pick(c, stream);
+    PoolLease lease(c, s);
     const gr80211_frame_desc *dd = nullptr;
     SchedTotals room = {};
     const bool no_wait = (flags & GR80211_FLAG_NO_WAIT) != 0;
@@ -824,6 +961,7 @@ int gr80211_rx_finish(gr80211_ctx *c, uint8_t *d_out, int out_stride, int32_t *d
     if (p.n > 0) HIP_TRY(c, hipSetDevice(c->device));
     c->pending.active = false;  // from here on the batch is spent, whatever the launches below return
     if (p.n == 0) return GR80211_OK;
+    PoolLease lease(c, p.stream);
     int rc = finish_decode_stages(c, p.stream, p.n, true, p.iq0, p.iq1, p.arena_len, p.desc, nullptr, d_out, out_stride, d_out_len,
                                   d_n_pdu, nullptr, 0, true, nullptr, nullptr);
     if (rc) return rc;
@@ -903,6 +1041,7 @@ int gr80211_rx_capture(gr80211_ctx *c, const void *d_iq0, const void *d_iq1, uin
     std::swap(c->chan1, c->chan1_alt);
     if (d_iq1) std::swap(c->chan2, c->chan2_alt);
     mark(c, 1, s);
+    PoolLease lease(c, s);
     rc = run_decode_stages(c, s, nf, true, d_iq0, d_iq1, n_samples, d_sel, nullptr, d_out, out_stride, d_out_len, d_n_pdu, nullptr, 0,
                            true, nullptr, nullptr);
     if (rc) return rc;
@@ -1058,6 +1197,7 @@ int gr80211_decode_batch(gr80211_ctx *c, const float *d_llr, uint64_t llr_floats
     mark(c, 0, s);
     launch_desc_to_info((const gr80211_dec_desc *)dd, n, llr_floats, (gr80211_frame_info *)c->info.p, s);
     mark(c, 1, s);
+    PoolLease lease(c, s);
     rc = run_decode_stages(c, s, n, false, nullptr, nullptr, 0, nullptr, d_llr, d_out, out_stride, d_out_len, d_n_pdu,
                            d_bits, bits_stride, true, nullptr, nullptr, on_host ? &known : nullptr);
     if (rc) return rc;
@@ -1208,6 +1348,7 @@ int gr80211_rx_resume(gr80211_ctx *c, const void *d_iq0, const void *d_iq1, uint
     if (d_iq1) std::swap(c->chan2, c->chan2_alt);
     c->signal_n = 0;
     mark(c, 1, s);
+    PoolLease lease(c, s);
     rc = run_decode_stages(c, s, n, true, d_iq0, d_iq1, arena_len, (const gr80211_frame_desc *)c->desc.p, nullptr, d_out, out_stride,
                            d_out_len, d_n_pdu, nullptr, 0, true, nullptr, nullptr, &known);
     if (rc) return rc;
@@ -1545,6 +1686,35 @@ int gr80211_copy_d2d(gr80211_ctx *c, void *d_dst, const void *d_src, size_t byte
     hipStream_t s = pick(c, stream);
     HIP_TRY(c, hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, s));
     HIP_TRY(c, hipStreamSynchronize(s));
+    return GR80211_OK;
+}
+
+int gr80211_use_work_pool(gr80211_ctx *c, int max_sets)
+{
+    if (!c || max_sets < 0 || max_sets > 64) return GR80211_ERR_ARG;
+    if (c->pending.active) return fail(c, GR80211_ERR_ARG, "gr80211_use_work_pool: a submitted batch is waiting for gr80211_rx_finish");
+    if (max_sets == 0) {
+        pool_leave(c);
+        return GR80211_OK;
+    }
+    std::lock_guard<std::mutex> lk(g_pool_mutex);
+    DevicePool &dp = g_pool[c->device];
+    if (c->pool_sets <= 0) dp.users++;
+    c->pool_sets = max_sets;
+    if (max_sets > dp.max_sets) dp.max_sets = max_sets;
+    return GR80211_OK;
+}
+
+int gr80211_work_memory(gr80211_ctx *c, uint64_t *own_bytes, uint64_t *pool_bytes, int *pool_sets)
+{
+    if (!c) return GR80211_ERR_ARG;
+    if (own_bytes) *own_bytes = (uint64_t)c->llr.cap + c->dec.cap + c->bitsw.cap;
+    std::lock_guard<std::mutex> lk(g_pool_mutex);
+    const DevicePool &dp = g_pool[c->device];
+    uint64_t b = 0;
+    for (const WorkSet *w : dp.sets) b += (uint64_t)w->llr.cap + w->dec.cap + w->bitsw.cap;
+    if (pool_bytes) *pool_bytes = b;
+    if (pool_sets) *pool_sets = (int)dp.sets.size();
     return GR80211_OK;
 }
 

@@ -75,7 +75,7 @@ EXPORTS = [
     "gr80211_rx_submit", "gr80211_rx_finish", "gr80211_decode_batch_noalloc", "gr80211_rx_resume",
     "gr80211_last_batch_refused", "gr80211_copy_h2d_async", "gr80211_copy_d2h_async", "gr80211_copy_d2d_async", "gr80211_pull_h2d", "gr80211_pull_done", "gr80211_push_d2h", "gr80211_get_stream",
     "gr80211_stream_idle", "gr80211_stream_wait", "gr80211_marker_record", "gr80211_marker_done",
-    "gr80211_host_register", "gr80211_host_unregister", "gr80211_pack_pdus",
+    "gr80211_host_register", "gr80211_host_unregister", "gr80211_pack_pdus", "gr80211_use_work_pool", "gr80211_work_memory",
 ]
 
 _lib = None
@@ -143,6 +143,8 @@ def load_library():
     L.gr80211_copy_d2h.argtypes = [vp, vp, vp, C.c_size_t, vp]
     L.gr80211_set_profiling.argtypes = [vp, C.c_int]
     L.gr80211_set_mu_pos.argtypes = [vp, C.c_int]
+    L.gr80211_use_work_pool.argtypes = [vp, C.c_int]
+    L.gr80211_work_memory.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_int)]
     L.gr80211_set_ampdu_strict.argtypes = [vp, C.c_int]
     L.gr80211_last_timing.argtypes = [vp, C.POINTER(C.c_float), C.c_int]
     L.gr80211_tx_samples.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
@@ -223,6 +225,16 @@ class RxContext:
 
     def set_profiling(self, on):
         self._check(self.lib.gr80211_set_profiling(self.h, 1 if on else 0), "set_profiling")
+
+    def use_work_pool(self, max_sets):
+        """Take the large work buffers from the GPU's shared pool of at most max_sets sets (0: own buffers again)."""
+        self._check(self.lib.gr80211_use_work_pool(self.h, int(max_sets)), "use_work_pool")
+
+    def work_memory(self):
+        """(bytes of the large work buffers this context holds, bytes of its GPU's pool, sets in the pool)."""
+        own, pool, sets = C.c_uint64(0), C.c_uint64(0), C.c_int(0)
+        self._check(self.lib.gr80211_work_memory(self.h, C.byref(own), C.byref(pool), C.byref(sets)), "work_memory")
+        return int(own.value), int(pool.value), int(sets.value)
 
     def set_mu_pos(self, pos):
         self._check(self.lib.gr80211_set_mu_pos(self.h, int(pos)), "set_mu_pos")

@@ -895,3 +895,62 @@ def test_copies_by_kernel_over_the_link(pkg, rxctx):
         lib.gr80211_dev_free(c, d)
         lib.gr80211_host_free(c, h_src)
         lib.gr80211_host_free(c, h_dst)
+
+
+def test_six_contexts_on_a_pool_of_three_work_sets(pkg):
+    """Six contexts take turns over batches of different sizes (as the benchmark's rotation does) while sharing
+    three sets of work buffers: every batch gives what a context with buffers of its own gives, with and without the
+    wait inside the call, the pool never holds more than three sets, and leaving it frees them."""
+    import torch
+    tx = pkg.txgen
+    rng = np.random.default_rng(61)
+    batches = []
+    for b in range(4):
+        frames = [make_noisy(tx, rng, int(rng.integers(0, 3)), int(rng.integers(0, 8)), 1, int(rng.integers(40, 1500)), 30.0)[0]
+                  for _ in range(int(rng.integers(90, 400)))]
+        iq0, _, sync, navail = build_arena(frames)
+        batches.append((torch.from_numpy(iq0).cuda(), torch.from_numpy(pkg.RxContext.make_desc(sync, navail).view(np.uint8).reshape(-1)).cuda(), len(frames)))
+    ref = pkg.RxContext(0)
+    want = []
+    for iq, desc, n in batches:
+        r = ref.rx_batch(iq, None, desc, n)
+        ref.sync()
+        want.append((r["out_len"].clone(), r["n_pdu"].clone(), r["out"].clone()))
+    ctxs = [pkg.RxContext(0) for _ in range(6)]
+    try:
+        for c in ctxs:
+            c.use_work_pool(3)
+        outs = [[(torch.zeros((n, 4104), dtype=torch.uint8, device="cuda"), torch.zeros(n, dtype=torch.int32, device="cuda"),
+                  torch.zeros(n, dtype=torch.int32, device="cuda")) for _, _, n in batches] for _ in ctxs]
+        for no_wait in (False, True, True):
+            for step in range(24):
+                k, b = step % 6, (step // 2) % 4
+                iq, desc, n = batches[b]
+                with torch.cuda.stream(ctxs[k].own_stream()):
+                    ctxs[k].rx_batch_into(iq, None, desc, n, *outs[k][b], no_wait=no_wait)
+            torch.cuda.synchronize()
+            for k, c in enumerate(ctxs):
+                assert not c.last_batch_refused()
+            for step in range(24):
+                k, b = step % 6, (step // 2) % 4
+                o, ol, npd = outs[k][b]
+                assert torch.equal(ol, want[b][0]) and torch.equal(npd, want[b][1])
+                keep = torch.arange(4104, device="cuda")[None, :] < ol[:, None]
+                assert torch.equal(o[keep], want[b][2][keep])
+                o.zero_(), ol.zero_(), npd.zero_()
+        own, pool, sets = ctxs[0].work_memory()
+        assert sets <= 3 and pool > 0
+        assert all(c.work_memory()[0] == 0 for c in ctxs)   # nobody grew buffers of its own
+        one = ref.work_memory()[0]
+        assert pool <= 3 * one * 1.05 + (1 << 20)
+        for c in ctxs:
+            c.use_work_pool(0)
+        assert ctxs[0].work_memory()[1:] == (0, 0)
+        # on its own again, a context grows its own buffers
+        iq, desc, n = batches[0]
+        ctxs[0].rx_batch_into(iq, None, desc, n, *outs[0][0])
+        ctxs[0].sync()
+        assert torch.equal(outs[0][0][1], want[0][0]) and ctxs[0].work_memory()[0] > 0
+    finally:
+        for c in ctxs + [ref]:
+            c.close()
