@@ -426,18 +426,34 @@ bool device_fifo::release_front(size_t items)
 
 void out_stream::push(const void *src, size_t items)
 {
-    if (d_head > (1u << 20) && d_head * 2 > d_buf.size()) {  // drop what has left
-        d_buf.erase(d_buf.begin(), d_buf.begin() + (long)d_head);
-        d_head = 0;
-    }
+    if (items == 0) return;
+    if (d_segs.empty() || d_segs.back().ext) d_segs.emplace_back();
+    seg &g = d_segs.back();
     const uint8_t *p = static_cast<const uint8_t *>(src);
-    d_buf.insert(d_buf.end(), p, p + items * d_item);
+    g.own.insert(g.own.end(), p, p + items * d_item);
+    g.bytes = g.own.size();
     d_pushed += items;
 }
 
 void out_stream::push_zeros(size_t items)
 {
-    d_buf.insert(d_buf.end(), items * d_item, 0);
+    if (items == 0) return;
+    if (d_segs.empty() || d_segs.back().ext) d_segs.emplace_back();
+    seg &g = d_segs.back();
+    g.own.insert(g.own.end(), items * d_item, 0);
+    g.bytes = g.own.size();
+    d_pushed += items;
+}
+
+void out_stream::push_ref(const void *src, size_t items, size_t *left)
+{
+    if (items == 0) return;
+    d_segs.emplace_back();
+    seg &g = d_segs.back();
+    g.ext = static_cast<const uint8_t *>(src);
+    g.bytes = items * d_item;
+    g.left = left;
+    if (left) *left += items;
     d_pushed += items;
 }
 
@@ -445,8 +461,18 @@ int out_stream::pop(void *dst, int max_items, uint64_t written, std::vector<tag_
 {
     const size_t n = std::min<size_t>(pending(), max_items > 0 ? (size_t)max_items : 0);
     if (n == 0) return 0;
-    memcpy(dst, d_buf.data() + d_head, n * d_item);
-    d_head += n * d_item;
+    uint8_t *d = static_cast<uint8_t *>(dst);
+    size_t want = n * d_item;
+    while (want > 0) {
+        seg &g = d_segs.front();
+        const size_t take = std::min(want, g.bytes - g.head);
+        memcpy(d, (g.ext ? g.ext : g.own.data()) + g.head, take);
+        g.head += take;
+        d += take;
+        want -= take;
+        if (g.left) *g.left -= take / d_item;
+        if (g.head == g.bytes) d_segs.pop_front();
+    }
     while (!d_tags.empty() && d_tags.front().offset < d_popped + n) {
         tag_t t = d_tags.front();
         t.offset = written + (t.offset - d_popped);
@@ -454,10 +480,6 @@ int out_stream::pop(void *dst, int max_items, uint64_t written, std::vector<tag_
         d_tags.pop_front();
     }
     d_popped += n;
-    if (d_head == d_buf.size()) {
-        d_buf.clear();
-        d_head = 0;
-    }
     return (int)n;
 }
 
@@ -1379,9 +1401,23 @@ demod::sptr demod::make(int n_rx, int mupos, int, int batch_frames, int device)
 
 demod::demod(int n_rx, int mupos, int batch_frames, int device)
     : block(n_rx == 2 ? 2 : 1, 1), d_nrx(n_rx == 2 ? 2 : 1), d_muPos(mupos ? 1 : 0), d_batch(batch_frames < 1 ? 1 : batch_frames),
-      d_gpu(device), d_iq0(d_gpu, sizeof(gr_complex)), d_iq1(d_gpu, sizeof(gr_complex)), d_out(sizeof(float))
+      d_device(device), d_out(sizeof(float))
 {
-    if (!d_gpu.ok()) d_err = "gr80211_create failed";
+    for (int i = 0; i < N_ROUNDS; i++) {
+        d_round.emplace_back(new round());
+        d_round.back()->gpu.reset(new gpu_session(device));
+        if (!d_round.back()->gpu->ok()) d_err = "gr80211_create failed";
+    }
+}
+
+demod::~demod()
+{
+    for (auto &r : d_round) {
+        if (r->worker.joinable()) r->worker.join();
+        for (int a = 0; a < 2; a++)
+            if (r->iq[a] && r->gpu->ok()) gr80211_host_free(r->gpu->ctx(), r->iq[a]);
+    }
+    unpin_all();
 }
 
 void demod::forecast(int noutput_items, gr_vector_int &ninput_items_required)
@@ -1390,15 +1426,62 @@ void demod::forecast(int noutput_items, gr_vector_int &ninput_items_required)
     for (int &v : ninput_items_required) v = d_out.pending() ? 0 : noutput_items;
 }
 
+demod::round *demod::free_round()
+{
+    for (auto &r : d_round)
+        if (r->state.load() == R_FREE) return r.get();
+    if ((int)d_round.size() >= MAX_ROUNDS) return nullptr;
+    d_round.emplace_back(new round());
+    d_round.back()->gpu.reset(new gpu_session(d_device));
+    if (!d_round.back()->gpu->ok()) {
+        d_round.pop_back();
+        return nullptr;
+    }
+    return d_round.back().get();
+}
+
+// Room for `items` items per antenna in the round's page-locked memory (what it holds moves along).
+bool demod::grow(round &r, size_t items)
+{
+    if (items <= r.cap) return true;
+    const size_t cap = std::max<size_t>(std::max<size_t>(2 * r.cap, items), (size_t)1 << 20);
+    gr80211_ctx *c = r.gpu->ctx();
+    for (int a = 0; a < d_nrx; a++) {
+        gr_complex *q = static_cast<gr_complex *>(gr80211_host_alloc(c, cap * sizeof(gr_complex)));
+        if (!q) {
+            d_err = "page-locked host memory exhausted";
+            return false;
+        }
+        if (r.n) memcpy(q, r.iq[a], r.n * sizeof(gr_complex));
+        if (r.iq[a]) gr80211_host_free(c, r.iq[a]);
+        r.iq[a] = q;
+    }
+    r.cap = cap;
+    return true;
+}
+
 int demod::general_work(int noutput_items, gr_vector_int &ninput_items, gr_vector_const_void_star &input_items,
                         gr_vector_void_star &output_items)
 {
     int n = ninput_items[0];
     if (d_nrx == 2) n = std::min(n, ninput_items[1]);
+    if (!harvest(false)) {
+        consume_each(0);
+        return 0;
+    }
     if (d_out.pending() > OUT_QUEUE_LIMIT) n = 0;  // input is only taken while the soft bits produced find room
     int used = 0;
     std::vector<tag_t> tags;
     while (used < n) {
+        if (!d_fill) {
+            d_fill = free_round();
+            if (!d_fill) break;  // every round is on its way: the input waits
+            d_fill->state.store(R_FILL);
+            d_fill->n = 0;
+            d_fill->desc.clear();
+            d_fill->chan.clear();
+        }
+        round &r = *d_fill;
         if (d_state == S_IDLE) {
             const uint64_t at = nitems_read(0) + (uint64_t)used;
             get_tags_in_range(tags, 0, at, at + 1);
@@ -1414,7 +1497,7 @@ int demod::general_work(int noutput_items, gr_vector_int &ninput_items, gr_vecto
             }
             gr80211_sig_desc d;
             memset(&d, 0, sizeof(d));
-            d.off = d_iq0.size();
+            d.off = r.n;
             d.mcs = (int32_t)tag_value(tags, "mcs", -1.0);
             d.len = (int32_t)tag_value(tags, "len", -1.0);
             d.nsamp = (int32_t)tag_value(tags, "nsamp", -1.0);
@@ -1429,23 +1512,22 @@ int demod::general_work(int noutput_items, gr_vector_int &ninput_items, gr_vecto
                 used++;
                 continue;
             }
-            d_desc.push_back(d);
-            d_chan.insert(d_chan.end(), ch->cvec.begin(), ch->cvec.begin() + 64);
+            r.desc.push_back(d);
+            r.chan.insert(r.chan.end(), ch->cvec.begin(), ch->cvec.begin() + 64);
             d_need = d.nsamp;
             d_skip = 320;  // lib/demod_impl.cc:92
             d_state = S_COLLECT;
         }
         if (d_state == S_COLLECT) {
             const int take = (int)std::min<long>(d_need, n - used);
-            for (int a = 0; a < d_nrx; a++) {
-                const gr_complex *s = static_cast<const gr_complex *>(input_items[(size_t)a]);
-                if (!iq(a).append(s + used, (size_t)take)) {
-                    d_err = "upload of the samples failed: " + d_gpu.error();
-                    consume_each(used);
-                    return 0;
-                }
+            if (!grow(r, r.n + (size_t)take + 64)) {
+                consume_each(used);
+                return 0;
             }
-            d_desc.back().n_avail += (uint32_t)take;
+            for (int a = 0; a < d_nrx; a++)
+                memcpy(r.iq[a] + r.n, static_cast<const gr_complex *>(input_items[(size_t)a]) + used, (size_t)take * sizeof(gr_complex));
+            r.n += (size_t)take;
+            r.desc.back().n_avail += (uint32_t)take;
             d_need -= take;
             used += take;
             if (d_need == 0) d_state = S_CLEAN;
@@ -1456,7 +1538,7 @@ int demod::general_work(int noutput_items, gr_vector_int &ninput_items, gr_vecto
             used += take;
             if (d_skip == 0) {
                 d_state = S_IDLE;
-                if ((int)d_desc.size() >= d_batch && !run_batch()) {
+                if ((int)r.desc.size() >= d_batch && !cut()) {
                     consume_each(used);
                     return 0;
                 }
@@ -1466,89 +1548,163 @@ int demod::general_work(int noutput_items, gr_vector_int &ninput_items, gr_vecto
     consume_each(used);
     if (output_items.empty()) return 0;
     tags.clear();
-    const int produced = d_out.pop(output_items[0], noutput_items, nitems_written(0), tags);
+    int produced = d_out.pop(output_items[0], noutput_items, nitems_written(0), tags);
+    if (used == 0 && produced == 0 && n > 0 && noutput_items > 0 && !d_flight.empty()) {
+        // Neither input taken (every round is on its way) nor output to give: the one case in which the call waits,
+        // for the oldest round, so that a caller never sees a call without progress while work is in flight (a
+        // scheduler would read that as the end of the stream).
+        if (!harvest_front()) return 0;
+        produced = d_out.pop(output_items[0], noutput_items, nitems_written(0), tags);
+    }
     for (const tag_t &t : tags) add_item_tag(0, t);
+    // rounds whose soft bits have all left are free again
+    while (!d_flight.empty() && d_flight.front()->state.load() == R_DRAIN && d_flight.front()->left == 0) {
+        d_flight.front()->state.store(R_FREE);
+        d_flight.pop_front();
+    }
     return produced;
+}
+
+// Waits for the oldest round that is still running and publishes what is ready.
+bool demod::harvest_front()
+{
+    for (round *rp : d_flight)
+        if (rp->state.load() != R_DRAIN) {
+            if (rp->worker.joinable()) rp->worker.join();
+            break;
+        }
+    return harvest(false);
 }
 
 bool demod::flush()
 {
     // a frame cut off by the end of the stream is demodulated with the items it has, like the fused block does
     d_state = S_IDLE;
-    return run_batch();
+    if (d_fill && !cut()) return false;
+    return harvest(true);
 }
 
-bool demod::run_batch()
+bool demod::cut()
 {
-    const int n = (int)d_desc.size();
-    if (n <= 0) return true;
-    if (!d_gpu.ok()) return false;
-    gr80211_ctx *c = d_gpu.ctx();
-    void *dch = d_gpu.buffer(0, (size_t)n * 64 * sizeof(gr_complex));
-    gr80211_frame_info *dinfo = static_cast<gr80211_frame_info *>(d_gpu.buffer(1, (size_t)n * sizeof(gr80211_frame_info)));
-    if (!dch || !dinfo) {
-        d_err = "device allocation failed";
-        return false;
+    round &r = *d_fill;
+    d_fill = nullptr;
+    if (r.desc.empty()) {
+        r.state.store(R_FREE);
+        return true;
     }
-    std::vector<gr80211_frame_info> info((size_t)n);
+    if (!r.gpu->ok()) return false;
+    d_nRounds++;
+    r.state.store(R_RUN);
+    d_flight.push_back(&r);
+    if (r.worker.joinable()) r.worker.join();
+    r.worker = std::thread([this, &r] { run(r); });
+    return true;
+}
+
+// The round's way through the GPU, on a thread of its own: every call here may wait.
+void demod::run(round &r)
+{
+    gpu_session &g = *r.gpu;
+    gr80211_ctx *c = g.ctx();
+    const int n = (int)r.desc.size();
+    r.err.clear();
+    r.ndp.clear();
+    r.info.assign((size_t)n, gr80211_frame_info());
+    r.llr = nullptr;
+    auto fail = [&](const std::string &what) {
+        r.err = what;
+        r.state.store(R_DONE);
+    };
+    char *d0 = static_cast<char *>(g.buffer(0, (r.n + 64) * sizeof(gr_complex)));
+    char *d1 = d_nrx == 2 ? static_cast<char *>(g.buffer(1, (r.n + 64) * sizeof(gr_complex))) : nullptr;
+    void *dch = g.buffer(2, (size_t)n * 64 * sizeof(gr_complex));
+    gr80211_frame_info *dinfo = static_cast<gr80211_frame_info *>(g.buffer(3, (size_t)n * sizeof(gr80211_frame_info)));
+    gr_complex *hch = static_cast<gr_complex *>(g.staging(1, (size_t)n * 64 * sizeof(gr_complex)));
+    gr80211_frame_info *hinfo = static_cast<gr80211_frame_info *>(g.staging(2, (size_t)n * sizeof(gr80211_frame_info)));
+    if (!d0 || (d_nrx == 2 && !d1) || !dch || !dinfo || !hch || !hinfo) return fail("allocation failed");
+    memcpy(hch, r.chan.data(), (size_t)n * 64 * sizeof(gr_complex));
     const float *dllr = nullptr;
     uint64_t nfl = 0;
-    if (gr80211_copy_h2d(c, dch, d_chan.data(), (size_t)n * 64 * sizeof(gr_complex), nullptr) != GR80211_OK ||
-        gr80211_demod_tagged_batch(c, d_iq0.data(), d_nrx == 2 ? d_iq1.data() : nullptr, d_iq0.size(), d_desc.data(), n, 0, dch,
-                                   dinfo, &dllr, &nfl, nullptr) != GR80211_OK ||
-        gr80211_copy_d2h(c, info.data(), dinfo, (size_t)n * sizeof(gr80211_frame_info), nullptr) != GR80211_OK) {
-        d_err = d_gpu.error();
-        return false;
-    }
-    float *llr = static_cast<float *>(d_gpu.staging(0, (size_t)(nfl + 1) * sizeof(float)));
-    if (!llr || (nfl && gr80211_copy_d2h(c, llr, dllr, (size_t)nfl * sizeof(float), nullptr) != GR80211_OK)) {
-        d_err = llr ? d_gpu.error() : std::string("page-locked host memory exhausted");
-        return false;
-    }
+    if (gr80211_copy_h2d_async(c, d0, r.iq[0], r.n * sizeof(gr_complex), nullptr) != GR80211_OK ||
+        (d_nrx == 2 && gr80211_copy_h2d_async(c, d1, r.iq[1], r.n * sizeof(gr_complex), nullptr) != GR80211_OK) ||
+        gr80211_copy_h2d_async(c, dch, hch, (size_t)n * 64 * sizeof(gr_complex), nullptr) != GR80211_OK ||
+        gr80211_demod_tagged_batch(c, d0, d1, r.n, r.desc.data(), n, 0, dch, dinfo, &dllr, &nfl, nullptr) != GR80211_OK ||
+        gr80211_copy_d2h_async(c, hinfo, dinfo, (size_t)n * sizeof(gr80211_frame_info), nullptr) != GR80211_OK)
+        return fail(g.error());
+    float *llr = static_cast<float *>(g.staging(0, (size_t)(nfl + 1) * sizeof(float)));
+    if (!llr) return fail("page-locked host memory exhausted");
+    if ((nfl && gr80211_copy_d2h_async(c, llr, dllr, (size_t)nfl * sizeof(float), nullptr) != GR80211_OK) || !g.sync())
+        return fail(g.error());
+    memcpy(r.info.data(), hinfo, (size_t)n * sizeof(gr80211_frame_info));
+    r.llr = llr;
     for (int i = 0; i < n; i++) {
-        const gr80211_frame_info &fi = info[(size_t)i];
-        const bool ndp = fi.status == GR80211_ST_NDP;
-        if (!(fi.status == GR80211_ST_OK || fi.status == GR80211_ST_DROP_DECODE_LIMIT || ndp)) continue;
-        // lib/demod_impl.cc:221-263, lib/demod2_impl.cc:228-258: the tags sit on the frame's first soft bit
-        tag_t t;
-        t.offset = d_out.pushed();
-        t.key = "cfo";     t.value = (double)fi.cfo_hz; d_out.tag(t);
-        t.key = "snr";     t.value = (double)fi.snr; d_out.tag(t);
-        if (fi.format == GR80211_F_VHT) {
-            t.key = "sssnr0"; t.value = (double)fi.sssnr0; d_out.tag(t);
-            if (d_nrx == 2 && fi.nSS == 2) { t.key = "sssnr1"; t.value = (double)fi.sssnr1; d_out.tag(t); }
-        }
-        t.key = "rssi";    t.value = (double)fi.rssi; d_out.tag(t);
-        t.key = "format";  t.value = (double)fi.format; d_out.tag(t);
-        t.key = "mcs";     t.value = (double)fi.mcs; d_out.tag(t);
-        t.key = "len";     t.value = (double)fi.len; d_out.tag(t);
-        t.key = "cr";      t.value = (double)fi.cr; d_out.tag(t);
-        t.key = "ampdu";   t.value = (double)fi.ampdu; d_out.tag(t);
-        t.key = "trellis"; t.value = (double)(ndp ? 0 : fi.trellis); d_out.tag(t);
-        if (ndp) {
-            // sounding frame: the raw samples of the two VHT-LTF windows travel in a tag, 1024 items carry nothing
-            // (lib/demod_impl.cc:238-249,265-271)
-            std::vector<gr_complex> win(128);
-            const uint64_t base = d_desc[(size_t)i].off + (uint64_t)fi.data_off + 8;
-            bool ok = true;
-            for (int w = 0; w < 2 && ok; w++)
-                ok = base + (uint64_t)w * 80 + 64 <= d_iq0.size() &&
-                     gr80211_copy_d2h(c, win.data() + w * 64,
-                                      static_cast<const gr_complex *>(d_iq0.data()) + base + (uint64_t)w * 80,
-                                      64 * sizeof(gr_complex), nullptr) == GR80211_OK;
-            t.key = "mu2x1chan"; t.value = 0.0; t.cvec = win; d_out.tag(t);
-            t.cvec.clear();
-            t.key = "total"; t.value = 1024.0; d_out.tag(t);
-            d_out.push_zeros(1024);
-            continue;
-        }
-        t.key = "total";   t.value = (double)fi.total; d_out.tag(t);
-        d_out.push(llr + fi.llr_off, (size_t)fi.total);
+        const gr80211_frame_info &fi = r.info[(size_t)i];
+        if (fi.status != GR80211_ST_NDP) continue;
+        // sounding frame: the raw samples of the two VHT-LTF windows (lib/demod_impl.cc:238-249,265-271)
+        std::vector<gr_complex> win(128);
+        const uint64_t base = r.desc[(size_t)i].off + (uint64_t)fi.data_off + 8;
+        for (int w = 0; w < 2; w++)
+            if (base + (uint64_t)w * 80 + 64 <= r.n) memcpy(win.data() + w * 64, r.iq[0] + base + (uint64_t)w * 80, 64 * sizeof(gr_complex));
+        r.ndp.push_back(std::move(win));
     }
-    d_desc.clear();
-    d_chan.clear();
-    d_iq0.clear();
-    d_iq1.clear();
+    r.state.store(R_DONE);
+}
+
+// Finished rounds, oldest first, hand their soft bits and tags to the output queue.
+bool demod::harvest(bool wait)
+{
+    for (round *rp : d_flight) {
+        round &r = *rp;
+        int st = r.state.load();
+        if (st == R_DRAIN) continue;
+        if (st == R_RUN && !wait) break;
+        if (r.worker.joinable()) r.worker.join();  // R_DONE, or waiting for it
+        if (!r.err.empty()) {
+            d_err = r.err;
+            return false;
+        }
+        const int n = (int)r.desc.size();
+        size_t ndp_at = 0;
+        r.left = 0;
+        for (int i = 0; i < n; i++) {
+            const gr80211_frame_info &fi = r.info[(size_t)i];
+            const bool ndp = fi.status == GR80211_ST_NDP;
+            if (!(fi.status == GR80211_ST_OK || fi.status == GR80211_ST_DROP_DECODE_LIMIT || ndp)) continue;
+            // lib/demod_impl.cc:221-263, lib/demod2_impl.cc:228-258: the tags sit on the frame's first soft bit
+            tag_t t;
+            t.offset = d_out.pushed();
+            t.key = "cfo";     t.value = (double)fi.cfo_hz; d_out.tag(t);
+            t.key = "snr";     t.value = (double)fi.snr; d_out.tag(t);
+            if (fi.format == GR80211_F_VHT) {
+                t.key = "sssnr0"; t.value = (double)fi.sssnr0; d_out.tag(t);
+                if (d_nrx == 2 && fi.nSS == 2) { t.key = "sssnr1"; t.value = (double)fi.sssnr1; d_out.tag(t); }
+            }
+            t.key = "rssi";    t.value = (double)fi.rssi; d_out.tag(t);
+            t.key = "format";  t.value = (double)fi.format; d_out.tag(t);
+            t.key = "mcs";     t.value = (double)fi.mcs; d_out.tag(t);
+            t.key = "len";     t.value = (double)fi.len; d_out.tag(t);
+            t.key = "cr";      t.value = (double)fi.cr; d_out.tag(t);
+            t.key = "ampdu";   t.value = (double)fi.ampdu; d_out.tag(t);
+            t.key = "trellis"; t.value = (double)(ndp ? 0 : fi.trellis); d_out.tag(t);
+            if (ndp) {
+                // the raw window samples travel in a tag, 1024 items carry nothing
+                t.key = "mu2x1chan"; t.value = 0.0;
+                if (ndp_at < r.ndp.size()) t.cvec = r.ndp[ndp_at++];
+                d_out.tag(t);
+                t.cvec.clear();
+                t.key = "total"; t.value = 1024.0; d_out.tag(t);
+                d_out.push_zeros(1024);
+                continue;
+            }
+            t.key = "total";   t.value = (double)fi.total; d_out.tag(t);
+            d_out.push_ref(r.llr + fi.llr_off, (size_t)fi.total, &r.left);
+        }
+        r.state.store(R_DRAIN);
+    }
+    while (!d_flight.empty() && d_flight.front()->state.load() == R_DRAIN && d_flight.front()->left == 0) {
+        d_flight.front()->state.store(R_FREE);
+        d_flight.pop_front();
+    }
     return true;
 }
 

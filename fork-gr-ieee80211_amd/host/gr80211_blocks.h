@@ -24,7 +24,9 @@
 #include <cstdint>
 #include <deque>
 #include <functional>
+#include <atomic>
 #include <memory>
+#include <thread>
 #include <string>
 #include <utility>
 #include <vector>
@@ -232,23 +234,31 @@ private:
 };
 
 // Items a block has produced and the scheduler has not yet made room for, with their tags (offsets count the
-// items ever pushed).
+// items ever pushed).  Items are copied in (push) or stay where they are (push_ref: memory the caller keeps
+// untouched until the items have left, e.g. the page-locked area a batch's results were copied to; `left`, if
+// given, counts the referenced items that have not left yet).
 class out_stream
 {
 public:
     explicit out_stream(size_t item_bytes) : d_item(item_bytes) {}
     uint64_t pushed() const { return d_pushed; }
-    size_t pending() const { return (d_buf.size() - d_head) / d_item; }
+    size_t pending() const { return (size_t)(d_pushed - d_popped); }
     void push(const void *src, size_t items);
     void push_zeros(size_t items);
+    void push_ref(const void *src, size_t items, size_t *left = nullptr);
     void tag(const tag_t &t) { d_tags.push_back(t); }  // t.offset = index among the pushed items
     // up to max_items into dst; their tags into `out`, re-based to the port's absolute offset `written`
     int pop(void *dst, int max_items, uint64_t written, std::vector<tag_t> &out);
 
 private:
+    struct seg {
+        const uint8_t *ext = nullptr;  // referenced items (nullptr: own holds them)
+        std::vector<uint8_t> own;
+        size_t bytes = 0, head = 0;    // size and what has left
+        size_t *left = nullptr;
+    };
     size_t d_item;
-    std::vector<uint8_t> d_buf;
-    size_t d_head = 0;         // bytes of d_buf already popped
+    std::deque<seg> d_segs;
     uint64_t d_pushed = 0, d_popped = 0;
     std::deque<tag_t> d_tags;
 };
@@ -466,31 +476,58 @@ class demod : public block
 public:
     typedef std::shared_ptr<demod> sptr;
     static sptr make(int n_rx = 1, int mupos = 0, int mugid = 2, int batch_frames = 4096, int device = 0);
-    ~demod() override { unpin_all(); }
+    ~demod() override;
     void forecast(int noutput_items, gr_vector_int &ninput_items_required) override;
     int general_work(int noutput_items, gr_vector_int &ninput_items, gr_vector_const_void_star &input_items,
                      gr_vector_void_star &output_items) override;
     bool flush() override;
     size_t pending_output() const { return d_out.pending(); }
     uint64_t frames_seen() const { return d_nSeen; }
+    uint64_t rounds_cut() const { return d_nRounds; }
     void set_mu_pos(int pos) { d_muPos = pos ? 1 : 0; }
 
 protected:
-    gr80211_ctx *pin_context() override { return d_gpu.ctx(); }
+    gr80211_ctx *pin_context() override { return !d_round.empty() && d_round[0]->gpu ? d_round[0]->gpu->ctx() : nullptr; }
 
 private:
     demod(int n_rx, int mupos, int batch_frames, int device);
-    bool run_batch();
-    int d_nrx, d_muPos, d_batch;
-    gpu_session d_gpu;
-    device_fifo d_iq0, d_iq1;
-    device_fifo &iq(int a) { return a ? d_iq1 : d_iq0; }
+    // One batch of frames on its way through the GPU.  While one round collects the frames that arrive (their items
+    // go to page-locked memory of the round), the rounds before it run on contexts and host threads of their own --
+    // upload, demodulator, soft bits back to page-locked memory -- and are published in order; general_work waits
+    // for none of them.  A round's soft bits leave for the scheduler's buffers straight from that memory, so the
+    // round is free again once the last of them has left.
+    struct round {
+        std::unique_ptr<gpu_session> gpu;
+        gr_complex *iq[2] = {nullptr, nullptr};  // page-locked: the frames' items back to back
+        size_t cap = 0, n = 0;                   // items they can hold / hold
+        std::vector<gr80211_sig_desc> desc;      // one per frame
+        std::vector<gr_complex> chan;            // 64 per frame
+        std::vector<gr80211_frame_info> info;    // results: one record per frame ...
+        const float *llr = nullptr;              // ... and the soft bits, page-locked
+        std::vector<std::vector<gr_complex>> ndp;  // raw VHT-LTF windows of sounding frames, in frame order
+        std::thread worker;
+        std::atomic<int> state{0};               // FREE, FILL, RUN, DONE (results there), DRAIN (soft bits leaving)
+        size_t left = 0;                         // soft bits of the round the scheduler has not taken yet
+        std::string err;
+    };
+    enum { R_FREE = 0, R_FILL, R_RUN, R_DONE, R_DRAIN };
+    bool grow(round &r, size_t items);
+    bool cut();                  // the round being filled goes to its worker; another one is filled (if one is free)
+    void run(round &r);          // worker thread: everything that waits for the GPU
+    bool harvest(bool wait);     // publish finished rounds in order; wait: for every round in flight
+    bool harvest_front();        // the same after waiting for the oldest round still running
+    round *free_round();
+    int d_nrx, d_muPos, d_batch, d_device;
+    // Three rounds to begin with (one filling, two on their way); more are made when the soft bits of finished rounds
+    // leave slowly (small output buffers), up to MAX_ROUNDS, so that input is only refused for lack of output room.
+    static constexpr int N_ROUNDS = 3, MAX_ROUNDS = 16;
+    std::vector<std::unique_ptr<round>> d_round;
+    round *d_fill = nullptr;
+    std::deque<round *> d_flight;           // rounds running or draining, oldest first
     enum { S_IDLE, S_COLLECT, S_CLEAN } d_state = S_IDLE;
     long d_need = 0, d_skip = 0;            // items of the current frame still to collect / to pass over
-    std::vector<gr80211_sig_desc> d_desc;   // one per pending frame
-    std::vector<gr_complex> d_chan;         // 64 per pending frame
     out_stream d_out;
-    uint64_t d_nSeen = 0;
+    uint64_t d_nSeen = 0, d_nRounds = 0;
 };
 
 // Whole receive flowgraph of examples/rx.grc / rx2.grc: inputs are the antenna streams only ({c64} or {c64, c64});
