@@ -457,6 +457,19 @@ void out_stream::push_ref(const void *src, size_t items, size_t *left)
     d_pushed += items;
 }
 
+void out_stream::release_refs(const void *lo, const void *hi)
+{
+    for (seg &g : d_segs) {
+        if (!g.ext || g.ext < static_cast<const uint8_t *>(lo) || g.ext >= static_cast<const uint8_t *>(hi)) continue;
+        g.own.assign(g.ext + g.head, g.ext + g.bytes);
+        g.bytes -= g.head;
+        g.head = 0;
+        g.ext = nullptr;
+        if (g.left) *g.left -= g.bytes / d_item;
+        g.left = nullptr;
+    }
+}
+
 int out_stream::pop(void *dst, int max_items, uint64_t written, std::vector<tag_t> &out)
 {
     const size_t n = std::min<size_t>(pending(), max_items > 0 ? (size_t)max_items : 0);
@@ -1336,38 +1349,64 @@ int signal::general_work(int noutput_items, gr_vector_int &ninput_items, gr_vect
     return produced;
 }
 
-// signal: the frames' items and tags go to the output queues (at once: the items leave as the scheduler makes room)
+// signal: the round's items are written and sent to page-locked memory of the round; nothing is waited for
 bool signal::start_frames(round &r)
 {
     // the round's own context runs the batch: its stream holds the samples' copies
     gpu_session &d_gpu = *r.gpu;
+    const int ri = (int)(&r - d_round);
     const void *diq0 = r.iq[0], *diq1 = d_nrx == 2 ? r.iq[1] : nullptr;
     const size_t nheld = r.n;
     std::vector<gr80211_frame_desc> &fd = r.fd;
     const std::vector<frame_ref> &fr = r.fr;
     gr80211_ctx *c = d_gpu.ctx();
     const int nf = (int)fd.size();
-    std::vector<uint64_t> off((size_t)nf + 1, 0);
+    std::vector<uint64_t> &off = d_off[ri];
+    off.assign((size_t)nf + 1, 0);
     for (int i = 0; i < nf; i++) off[(size_t)i + 1] = off[(size_t)i] + (uint64_t)fr[(size_t)i].nsamp + 320u;
     const uint64_t total = off[(size_t)nf];
+    // items of this round's last turn that the scheduler has not taken yet move out of the memory about to be rewritten
+    if (d_left[ri]) {
+        d_out0.release_refs(d_span[ri][0].lo, d_span[ri][0].hi);
+        d_out1.release_refs(d_span[ri][1].lo, d_span[ri][1].hi);
+    }
     void *do0 = d_gpu.buffer(3, (size_t)(total + 64) * sizeof(gr_complex));
     void *do1 = d_nrx == 2 ? d_gpu.buffer(4, (size_t)(total + 64) * sizeof(gr_complex)) : nullptr;
     void *dch = d_gpu.buffer(5, (size_t)nf * 64 * sizeof(gr_complex));
     gr_complex *h0 = static_cast<gr_complex *>(d_gpu.staging(0, (size_t)total * sizeof(gr_complex) + 8));
     gr_complex *h1 = d_nrx == 2 ? static_cast<gr_complex *>(d_gpu.staging(1, (size_t)total * sizeof(gr_complex) + 8)) : nullptr;
-    gr_complex *hch = static_cast<gr_complex *>(d_gpu.staging(2, (size_t)nf * 64 * sizeof(gr_complex)));
+    gr_complex *hch = static_cast<gr_complex *>(d_gpu.staging(3, (size_t)nf * 64 * sizeof(gr_complex)));
     if (!do0 || (d_nrx == 2 && (!do1 || !h1)) || !dch || !h0 || !hch) {
         d_err = "allocation of the output buffers failed";
         return false;
     }
+    d_span[ri][0].lo = reinterpret_cast<const char *>(h0);
+    d_span[ri][0].hi = reinterpret_cast<const char *>(h0 + total) + 8;
+    d_span[ri][1].lo = reinterpret_cast<const char *>(h1);
+    d_span[ri][1].hi = h1 ? reinterpret_cast<const char *>(h1 + total) + 8 : nullptr;
     if (gr80211_signal_emit_batch(c, diq0, diq1, nheld, fd.data(), nf, 0, off.data(), do0, do1, total, nullptr, dch,
                                   nullptr) != GR80211_OK ||
-        gr80211_copy_d2h(c, h0, do0, (size_t)total * sizeof(gr_complex), nullptr) != GR80211_OK ||
-        (d_nrx == 2 && gr80211_copy_d2h(c, h1, do1, (size_t)total * sizeof(gr_complex), nullptr) != GR80211_OK) ||
-        gr80211_copy_d2h(c, hch, dch, (size_t)nf * 64 * sizeof(gr_complex), nullptr) != GR80211_OK) {
+        gr80211_push_d2h(c, h0, do0, (size_t)total * sizeof(gr_complex), nullptr) != GR80211_OK ||
+        (d_nrx == 2 && gr80211_push_d2h(c, h1, do1, (size_t)total * sizeof(gr_complex), nullptr) != GR80211_OK) ||
+        gr80211_push_d2h(c, hch, dch, (size_t)nf * 64 * sizeof(gr_complex), nullptr) != GR80211_OK) {
         d_err = d_gpu.error();
         return false;
     }
+    return true;
+}
+
+// signal: the round's stream has run dry, its items and channel estimates are in the round's page-locked memory
+bool signal::finish_frames(round &r)
+{
+    gpu_session &d_gpu = *r.gpu;
+    const int ri = (int)(&r - d_round);
+    const std::vector<frame_ref> &fr = r.fr;
+    const int nf = (int)r.fd.size();
+    const std::vector<uint64_t> &off = d_off[ri];
+    const uint64_t total = off[(size_t)nf];
+    const gr_complex *h0 = static_cast<const gr_complex *>(d_gpu.staging(0, (size_t)total * sizeof(gr_complex) + 8));
+    const gr_complex *h1 = d_nrx == 2 ? static_cast<const gr_complex *>(d_gpu.staging(1, (size_t)total * sizeof(gr_complex) + 8)) : nullptr;
+    const gr_complex *hch = static_cast<const gr_complex *>(d_gpu.staging(3, (size_t)nf * 64 * sizeof(gr_complex)));
     for (int i = 0; i < nf; i++) {
         const frame_ref &r = fr[(size_t)i];
         // lib/signal_impl.cc:133-152: the tags sit on the frame's first output item
@@ -1386,8 +1425,8 @@ bool signal::start_frames(round &r)
         t.cvec.assign(hch + (size_t)i * 64, hch + (size_t)i * 64 + 64);
         d_out0.tag(t);
         const size_t cnt = (size_t)r.nsamp + 320;
-        d_out0.push(h0 + off[(size_t)i], cnt);
-        if (d_nrx == 2) d_out1.push(h1 + off[(size_t)i], cnt);
+        d_out0.push_ref(h0 + off[(size_t)i], cnt, &d_left[ri]);
+        if (d_nrx == 2) d_out1.push_ref(h1 + off[(size_t)i], cnt, &d_left[ri]);
     }
     d_nFrames += (uint64_t)nf;
     return true;

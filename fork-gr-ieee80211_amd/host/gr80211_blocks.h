@@ -246,6 +246,8 @@ public:
     void push(const void *src, size_t items);
     void push_zeros(size_t items);
     void push_ref(const void *src, size_t items, size_t *left = nullptr);
+    // referenced items that lie in [lo, hi) are copied, so that the memory may be written again
+    void release_refs(const void *lo, const void *hi);
     void tag(const tag_t &t) { d_tags.push_back(t); }  // t.offset = index among the pushed items
     // up to max_items into dst; their tags into `out`, re-based to the port's absolute offset `written`
     int pop(void *dst, int max_items, uint64_t written, std::vector<tag_t> &out);
@@ -458,12 +460,20 @@ public:
 
 protected:
     signal(int n_rx, int batch_frames, int device);
+    // a round's items are written by the GPU and copied to page-locked memory of the round without the host waiting
+    // (start_frames); once the round's stream has run dry they are handed to the output queues by reference, with
+    // their tags (finish_frames), and leave for the scheduler's buffers from where they are
     bool start_frames(round &r) override;
-    bool finish_frames(round &) override { return true; }
+    bool finish_frames(round &r) override;
 
 private:
     out_stream d_out0, d_out1;
     long d_seq = 0;
+    std::vector<uint64_t> d_off[N_ROUNDS];  // per round: item offset of every frame in the round's output
+    size_t d_left[N_ROUNDS] = {};           // per round: items the output queues still reference
+    struct span {
+        const char *lo = nullptr, *hi = nullptr;
+    } d_span[N_ROUNDS][2];                  // per round and antenna: the page-locked memory they lie in
 };
 
 // ieee80211::demod(mupos, mugid) (n_rx = 1: in {c64}) and demod2 (n_rx = 2: in {c64, c64}), out {f32},

@@ -6,6 +6,9 @@
 //   gr80211_pump chain <n_rx> <chunk> <batch> <triggers.txt> <iq0.bin> [iq1.bin]
 //       the same input through three blocks, signal -> demod -> decode, joined by buffers of <chunk> items the
 //       way a flowgraph joins them
+//   gr80211_pump chaint <n_rx> <chunk> <batch> <triggers.txt> <iq0.bin> [iq1.bin]
+//       the three blocks on a thread each, as GNU Radio's thread-per-block scheduler runs them, joined by ring buffers
+//       of 32 windows in memory the reading block handed out (page-locked unless GR80211_PUMP_PIN=0)
 //   gr80211_pump capture <n_rx> <chunk> <iq0.bin> [iq1.bin]
 //       no sync stream: frame detection runs on the GPU as well
 //   gr80211_pump decode <chunk> <batch> <tags.txt> <llr.bin>
@@ -23,7 +26,11 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
+#include <atomic>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "gr80211_blocks.h"
@@ -152,6 +159,133 @@ struct link {
         }
     }
 };
+
+
+// A stream between two blocks that run on threads of their own: a ring of `cap` items that one thread writes and one
+// reads, followed by a mirror of its first `win` items, so that a window of up to `win` items is contiguous wherever
+// it starts.  Tags travel beside it under a lock.
+struct ring_link {
+    size_t item, cap, win;
+    char *buf = nullptr;
+    block *owner = nullptr;  // the block whose alloc_input made buf (nullptr: malloc)
+    std::atomic<uint64_t> w{0}, r{0};
+    std::atomic<bool> closed{false};  // the writer has finished
+    std::mutex m;
+    std::deque<tag_t> tags;
+    // mirror = false: a stream that is written once and read once from its start (a source) needs no mirror
+    ring_link(size_t it, size_t windows, size_t window_items, block *pin, bool mirror = true)
+        : item(it), cap(windows * window_items), win(mirror ? window_items : 0)
+    {
+        const size_t bytes = (cap + win) * item;
+        if (pin) buf = static_cast<char *>(pin->alloc_input(bytes));
+        if (buf) owner = pin;
+        else buf = static_cast<char *>(malloc(bytes));
+    }
+    ~ring_link()
+    {
+        if (owner) owner->free_input(buf);
+        else free(buf);
+    }
+    size_t readable() const { return (size_t)(w.load(std::memory_order_acquire) - r.load(std::memory_order_relaxed)); }
+    size_t writable() const { return cap - (size_t)(w.load(std::memory_order_relaxed) - r.load(std::memory_order_acquire)); }
+    const char *read_ptr() const { return buf + (r.load(std::memory_order_relaxed) % cap) * item; }
+    char *write_ptr() { return buf + (w.load(std::memory_order_relaxed) % cap) * item; }
+    // the writer has put n items at write_ptr(): keep ring and mirror alike, then publish
+    void commit(size_t n)
+    {
+        const size_t at = (size_t)(w.load(std::memory_order_relaxed) % cap);
+        // part of [at, at + n) below `win` goes to the mirror; part at or beyond `cap` (written into the mirror) goes to the front
+        if (at < win) memcpy(buf + (cap + at) * item, buf + at * item, std::min(n, win - at) * item);
+        if (at + n > cap) memcpy(buf, buf + cap * item, (at + n - cap) * item);
+        w.store(w.load(std::memory_order_relaxed) + n, std::memory_order_release);
+    }
+    void consume(size_t n) { r.store(r.load(std::memory_order_relaxed) + n, std::memory_order_release); }
+};
+
+// One block of a flowgraph on its own thread: calls general_work whenever there is input or room for output.
+static void run_block(block *b, std::vector<ring_link *> in, std::vector<ring_link *> out, int chunk, std::atomic<bool> *failed,
+                      const char *name)
+{
+    bool flushed = false;
+    std::vector<tag_t> tv;
+    double t_work = 0, t_idle = 0, t_flush = 0;  // where the thread's time went (GR80211_BLOCK_PROFILE)
+    unsigned long long n_calls = 0, n_idle = 0;
+    const bool profile = getenv("GR80211_BLOCK_PROFILE") != nullptr;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    for (;;) {
+        if (failed->load()) break;
+        size_t avail = ~(size_t)0, room = ~(size_t)0;
+        bool up_closed = true;
+        for (ring_link *l : in) {
+            up_closed = up_closed && l->closed.load(std::memory_order_acquire);
+            avail = std::min(avail, l->readable());
+        }
+        for (ring_link *l : out) room = std::min(room, l->writable());
+        if (in.empty()) avail = 0;
+        const int nin_items = (int)std::min<size_t>(avail, (size_t)chunk);
+        const int nout = out.empty() ? chunk : (int)std::min<size_t>(room, (size_t)chunk);
+        if (nin_items == 0 && up_closed && !flushed) {
+            const double tf = now();
+            if (!b->flush()) {
+                fprintf(stderr, "flush failed: %s\n", b->last_error().c_str());
+                failed->store(true);
+                break;
+            }
+            t_flush += now() - tf;
+            flushed = true;
+        }
+        const double tw = now();
+        gr_vector_int nin(in.size(), nin_items);
+        gr_vector_const_void_star ip(in.size());
+        gr_vector_void_star op(out.size());
+        b->clear_item_tags_in();
+        for (size_t p = 0; p < in.size(); p++) {
+            ip[p] = in[p]->read_ptr();
+            const uint64_t r0 = in[p]->r.load(std::memory_order_relaxed);
+            std::lock_guard<std::mutex> lk(in[p]->m);
+            while (!in[p]->tags.empty() && in[p]->tags.front().offset < r0) in[p]->tags.pop_front();
+            for (const tag_t &t : in[p]->tags) {
+                if (t.offset >= r0 + (uint64_t)nin_items) break;
+                b->add_item_tag_in((int)p, t);
+            }
+        }
+        for (size_t p = 0; p < out.size(); p++) op[p] = out[p]->write_ptr();
+        const int produced = (nout > 0 || out.empty()) ? b->general_work(nout, nin, ip, op) : 0;
+        const int used = (nout > 0 || out.empty()) ? b->consumed() : 0;
+        if (!b->last_error().empty()) {
+            fprintf(stderr, "block error: %s\n", b->last_error().c_str());
+            failed->store(true);
+            break;
+        }
+        for (size_t p = 0; p < out.size(); p++) {
+            tv = b->take_output_tags((int)p);
+            if (!tv.empty()) {
+                std::lock_guard<std::mutex> lk(out[p]->m);
+                for (tag_t &t : tv) out[p]->tags.push_back(std::move(t));
+            }
+            if (produced > 0) out[p]->commit((size_t)produced);
+        }
+        if (nout > 0 || out.empty()) b->commit(produced);
+        for (ring_link *l : in) l->consume((size_t)used);
+        n_calls++;
+        if (used || produced) t_work += now() - tw;
+        else t_idle += now() - tw;
+        if (used == 0 && produced == 0) {
+            n_idle++;
+            if (flushed && nin_items == 0) {
+                // everything upstream has been read and flushed: done once nothing is left to hand on
+                if (out.empty() || room > 0) break;  // with no room the block was not asked: ask again
+            }
+            const double ts = now();
+            std::this_thread::sleep_for(std::chrono::microseconds(20));
+            t_idle += now() - ts;
+        }
+    }
+    if (profile)
+        fprintf(stderr, "%-7s calls %llu (%llu without progress)  working %.3f s  idle %.3f s  flush %.3f s\n", name, n_calls, n_idle,
+                t_work, t_idle, t_flush);
+    for (ring_link *l : out) l->closed.store(true, std::memory_order_release);
+}
 
 // One general_work call of `b`: reads from `in` (all ports advance together), appends what it produces to `out`.
 static bool step(block &b, std::vector<link *> in, std::vector<link *> out, int chunk, bool &progress)
@@ -316,6 +450,71 @@ static int run(int argc, char **argv)
         printf("TIME items=%zu seconds=%.6f\n", n, g_seconds);
         return ok ? 0 : 1;
     }
+    if (argc >= 7 && !strcmp(argv[1], "chaint")) {
+        const int n_rx = atoi(argv[2]), chunk = atoi(argv[3]), batch = atoi(argv[4]);
+        std::vector<char> iq0, iq1;
+        if (!read_file(argv[6], iq0) || (n_rx == 2 && (argc < 8 || !read_file(argv[7], iq1)))) {
+            fprintf(stderr, "cannot read IQ file\n");
+            return 2;
+        }
+        size_t n = iq0.size() / 8;
+        if (n_rx == 2) n = std::min(n, iq1.size() / 8);
+        signal::sptr sg = signal::make(n_rx, batch, 0);
+        demod::sptr dm = demod::make(n_rx, 0, 2, batch, 0);
+        decode::sptr dc = decode::make(false, batch, 0);
+        dc->set_msg_handler(on_msg);
+        const char *pin = getenv("GR80211_PUMP_PIN");
+        const bool pinned = !pin || pin[0] != '0';
+        // the sources: whole streams, written before the clock starts (one "window" as long as the stream)
+        ring_link l_sync(1, 1, n + 1, nullptr, false), l_a(8, 1, n + 1, pinned ? sg.get() : nullptr, false),
+            l_b(8, 1, n_rx == 2 ? n + 1 : 1, pinned ? sg.get() : nullptr, false);
+        memset(l_sync.buf, 0, n + 1);
+        memcpy(l_a.buf, iq0.data(), n * 8);
+        if (n_rx == 2) memcpy(l_b.buf, iq1.data(), n * 8);
+        FILE *f = fopen(argv[5], "r");
+        if (!f) return 2;
+        unsigned long long pos;
+        float rad, snr, rssi;
+        std::vector<tag_t> trig;
+        while (fscanf(f, "%llu %f %f %f", &pos, &rad, &snr, &rssi) == 4) {
+            if (pos >= n) continue;
+            l_sync.buf[pos] = 1;
+            tag_t t;
+            t.offset = pos;
+            t.key = "rad"; t.value = rad; trig.push_back(t);
+            t.key = "snr"; t.value = snr; trig.push_back(t);
+            t.key = "rssi"; t.value = rssi; trig.push_back(t);
+        }
+        fclose(f);
+        std::stable_sort(trig.begin(), trig.end(), [](const tag_t &a, const tag_t &b) { return a.offset < b.offset; });
+        l_sync.tags.assign(trig.begin(), trig.end());
+        for (ring_link *l : {&l_sync, &l_a, &l_b}) {
+            l->w.store(n);
+            l->closed.store(true);
+        }
+        const size_t W = 32;
+        ring_link l_s0(8, W, (size_t)chunk, pinned ? dm.get() : nullptr), l_s1(8, W, (size_t)chunk, pinned ? dm.get() : nullptr),
+            l_llr(4, W, (size_t)chunk, pinned ? dc.get() : nullptr);
+        std::vector<ring_link *> in_sg = {&l_sync, &l_a}, out_sg = {&l_s0}, in_dm = {&l_s0};
+        if (n_rx == 2) {
+            in_sg.push_back(&l_b);
+            out_sg.push_back(&l_s1);
+            in_dm.push_back(&l_s1);
+        }
+        std::atomic<bool> failed{false};
+        const auto t0 = std::chrono::steady_clock::now();
+        std::thread t_sg(run_block, sg.get(), in_sg, out_sg, chunk, &failed, "signal");
+        std::thread t_dm(run_block, dm.get(), in_dm, std::vector<ring_link *>{&l_llr}, chunk, &failed, "demod");
+        std::thread t_dc(run_block, dc.get(), std::vector<ring_link *>{&l_llr}, std::vector<ring_link *>{}, chunk, &failed, "decode");
+        t_sg.join();
+        t_dm.join();
+        t_dc.join();
+        g_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        printf("STAT triggers=%llu frames=%llu pdus=%llu\n", (unsigned long long)sg->triggers_seen(),
+               (unsigned long long)sg->frames_decoded(), (unsigned long long)dc->pdus_published());
+        printf("TIME items=%zu seconds=%.6f\n", n, g_seconds);
+        return failed.load() ? 1 : 0;
+    }
     if (argc >= 5 && !strcmp(argv[1], "capture")) {
         const int n_rx = atoi(argv[2]), chunk = atoi(argv[3]);
         capture_rx::sptr b = capture_rx::make(n_rx, 0);
@@ -377,6 +576,7 @@ static int run(int argc, char **argv)
     fprintf(stderr, "usage: gr80211_pump [--udp host:port] <mode> ...\n"
                     "       gr80211_pump rx <n_rx> <chunk> <batch> <triggers.txt> <iq0.bin> [iq1.bin]\n"
                     "       gr80211_pump chain <n_rx> <chunk> <batch> <triggers.txt> <iq0.bin> [iq1.bin]\n"
+                    "       gr80211_pump chaint <n_rx> <chunk> <batch> <triggers.txt> <iq0.bin> [iq1.bin]\n"
                     "       gr80211_pump capture <n_rx> <chunk> <iq0.bin> [iq1.bin]\n"
                     "       gr80211_pump decode <chunk> <batch> <tags.txt> <llr.bin>\n");
     return 2;

@@ -596,3 +596,25 @@ def test_streaming_abi_from_plain_c(tmp_path, oracle, n_rx, chunk, batch):
     got, stat = run_pump([n_rx, chunk, batch, tf] + files, prog=ABI_CHAIN)
     assert got == want
     assert stat == "STAT pdus=%d" % len(want)
+
+
+def test_pump_chain_on_three_threads_equals_one_thread(pkg, tmp_path):
+    """gr80211_pump chaint (signal, demod and decode on a thread each, ring buffers between them, as GNU Radio's
+    scheduler runs a flowgraph) publishes the messages of gr80211_pump chain (the same blocks called in turn), in
+    the same order, with page-locked and with ordinary buffers."""
+    import subprocess
+    iq0, triggers, frames = siso_stream(0.002, 40)
+    f_iq, f_tr = str(tmp_path / "iq.bin"), str(tmp_path / "tr.txt")
+    iq0.astype(np.complex64).tofile(f_iq)
+    with open(f_tr, "w") as fh:
+        for pos, rad in sorted(triggers):
+            fh.write("%d %.9g 30.0 -40.0\n" % (pos, rad))
+    pump = os.path.join(ROOT, "fork-gr-ieee80211_amd", "gr80211_pump")
+    outs = {}
+    for mode, pin in (("chain", "1"), ("chaint", "1"), ("chaint", "0")):
+        r = subprocess.run([pump, mode, "1", "3000", "7", f_tr, f_iq], capture_output=True, text=True, timeout=300,
+                           env=dict(os.environ, GR80211_PUMP_PIN=pin))
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[(mode, pin)] = [l for l in r.stdout.splitlines() if l.startswith("PDU ") or l.startswith("STAT")]
+    assert len(outs[("chain", "1")]) > 5
+    assert outs[("chaint", "1")] == outs[("chain", "1")] and outs[("chaint", "0")] == outs[("chain", "1")]

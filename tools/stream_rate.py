@@ -73,8 +73,23 @@ def main():
     for pin in (True, False):
         for chunk, batch in ((8192, 4096), (65536, 4096), (65536, 16384), (1 << 18, 16384), (1 << 20, 16384)):
             run(["rx", 1, chunk, batch, f_tr, f_iq], ns, "rx      window %7d batch %5d" % (chunk, batch), pin)
-    if n <= 20000:
-        run(["chain", 1, 65536, 4096, f_tr, f_iq], ns, "signal->demod->decode, 65536/4096")
+    # the reference's three blocks as three blocks: one thread each (a flowgraph), and all on one thread
+    n_chain = min(n, 60000)
+    f_iqc = f_iq
+    if n_chain < n:
+        f_iqc = os.path.join(work, "iq0_chain.bin")
+        iq[: n_chain * L + 64].tofile(f_iqc)
+    f_trc = os.path.join(work, "trig_chain.txt")
+    with open(f_trc, "w") as fh:
+        for p in sync[:n_chain].tolist():
+            fh.write("%d 0.0 30.0 -40.0\n" % p)
+    for pin in (True, False):
+        for chunk, batch in ((65536, 4096), (1 << 18, 4096), (1 << 20, 8192)):
+            run(["chaint", 1, chunk, batch, f_trc, f_iqc], n_chain * L, "chain, 3 threads window %7d batch %5d" % (chunk, batch), pin)
+    if n_chain <= 60000:
+        run(["chain", 1, 65536, 4096, f_trc, f_iqc], n_chain * L, "chain, 1 thread  window   65536 batch  4096")
+    for f in (f_trc,) + ((f_iqc,) if f_iqc != f_iq else ()):
+        os.remove(f)
     run(["capture", 1, 65536, f_iq], ns, "capture window   65536")
     for pin in (True, False):
         for chunk, batch in ((65536, 4096), (65536, 16384), (1 << 18, 16384), (1 << 20, 16384)):
