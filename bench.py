@@ -306,16 +306,17 @@ def cpu_baseline(arena_host, arena1_host, sync, navail, n_sample, gpu_blobs, bud
 
 def measured_counters(workload, n):
     """Per-launch hardware counters of the dominant kernels from the committed rocprofv3 passes
-    (profiles/counters.json, written by tools/make_counters_json.py from the pass summaries beside it), if they were
-    taken on this workload and batch size; None otherwise."""
-    path = os.path.join(ROOT, "profiles", "counters.json")
-    try:
-        with open(path) as f:
-            t = json.load(f)
-        if t.get("workload") == workload and t.get("frames") == n:
-            return t
-    except (OSError, ValueError):
-        pass
+    (profiles/counters_<workload>.json, or profiles/counters.json for the headline workload; written by
+    tools/make_counters_json.py from the pass summaries beside them), if they were taken on this workload and batch size;
+    None otherwise."""
+    for name in ("counters_%s.json" % workload, "counters.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                t = json.load(f)
+            if t.get("workload") == workload and t.get("frames") == n:
+                return t
+        except (OSError, ValueError):
+            pass
     return None
 
 

@@ -98,6 +98,8 @@ struct gr80211_ctx {
     int group_waves = -1;       // GR80211_GROUP_WAVES=1|2|4: wavefronts per decoder group (-1: by batch size); 10: one, in the
                                 // form batches of more than 1024 groups take (k_decode_lean) whatever the size; 64: one
                                 // wavefront per frame (lane = trellis state)
+    bool axis_llr = false;      // GR80211_AXIS_LLR=1 (experiment): the demodulator leaves one value per constellation axis, the
+                                // one-wave decoder folds the soft bits out of it; batches of one modulation per group only
     int lane_state_max = 14000;  // batches of at most this many frames take the one-wavefront-per-frame form
                                 // (GR80211_LANE_STATE_MAX; 0 switches the form off)
     hipEvent_t ev[7] = {};
@@ -425,7 +427,8 @@ int finish_decode_stages(gr80211_ctx *c, hipStream_t s, int n, bool from_iq, con
     if (c->lease) c->lease->engage();  // the kernels from here on use the (possibly shared) work buffers
     if (from_iq) {
         if ((rc = ensure(c, c->llr, (size_t)(tot.llr_floats + 64) * sizeof(float)))) return rc;
-        launch_demod(d_iq0, d_iq1, arena_len, d_desc, n, info, c->chan1.p, c->chan2.p, (float *)c->llr.p, dt, s);
+        launch_demod(d_iq0, d_iq1, arena_len, d_desc, n, info, c->chan1.p, c->chan2.p, (float *)c->llr.p, dt, s,
+                     c->axis_llr && decode);
         llr = (const float *)c->llr.p;
     }
     if (llr_used) *llr_used = llr;
@@ -445,6 +448,8 @@ int finish_decode_stages(gr80211_ctx *c, hipStream_t s, int n, bool from_iq, con
             if (gw == 10) gw = 1;  // one wave per group in the form large batches take
             // few frames: one wave per frame, one state per lane (the frame count is exact when it comes from the
             // scheduler, an upper bound when the batch was launched without waiting for it)
+            const bool axis = c->axis_llr && from_iq;  // soft bits handed in from outside are soft bits
+            if (axis) gw = 1;                           // only the one-wave form has the folding loader
             if (gw != 1 && gw != 2 && gw != 4 && gw != 64)
                 gw = tot.n_valid <= c->lane_state_max ? 64 : tot.n_groups <= 512 ? 4 : tot.n_groups <= 1024 ? 2 : 1;
             if (gw == 64) {
@@ -479,7 +484,7 @@ int finish_decode_stages(gr80211_ctx *c, hipStream_t s, int n, bool from_iq, con
                 // one kernel: the timing slot of the forward pass then covers the traceback as well
                 launch_decode(llr, info, (const int32_t *)c->slot_frame.p, (const GroupInfo *)c->groups.p,
                               tot.n_groups, (uint32_t *)c->dec.p, (uint32_t *)c->bitsw.p, d_out, out_stride,
-                              d_out_len, d_n_pdu, d_bits, bits_stride, c->ampdu_strict, dt, c->group_waves == 10, s);
+                              d_out_len, d_n_pdu, d_bits, bits_stride, c->ampdu_strict, dt, c->group_waves == 10, s, axis);
                 mark(c, 4, s);
             }
         } else {
@@ -812,6 +817,7 @@ int gr80211_create(gr80211_ctx **out, int device)
     if (const char *e = getenv("GR80211_SPLIT_DECODE")) c->split_decode = e[0] == '1';
     if (const char *e = getenv("GR80211_GROUP_WAVES")) c->group_waves = atoi(e);
     if (const char *e = getenv("GR80211_LANE_STATE_MAX")) c->lane_state_max = atoi(e);
+    if (const char *e = getenv("GR80211_AXIS_LLR")) c->axis_llr = e[0] == '1';
     if (const char *e = getenv("GR80211_WORK_POOL")) {
         const int sets = atoi(e);
         if (sets > 0) (void)gr80211_use_work_pool(c, sets);

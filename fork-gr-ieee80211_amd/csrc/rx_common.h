@@ -26,6 +26,9 @@ struct Tables {
     int16_t deint_l[4][288];   // out[map[j]] = in[j]                             17.3.5.7
     int16_t deint_nl[5][416];  //                                                 19.3.11.8.x
     int16_t deint_nl2[5][416]; // second spatial stream (rotation 11)
+    int16_t intl_l[4][288];    // the interleavers themselves: coded bit k is sent at position map[k]
+    int16_t intl_nl[5][416];
+    int16_t intl_nl2[5][416];
     float tw_re[32], tw_im[32];// exp(-2*pi*i*k/64)
     uint32_t crc[256];         // reflected CRC-32 0xEDB88320
 };

@@ -56,7 +56,7 @@ void launch_pre_gather(const int32_t *path, int n, const gr80211_frame_info *inf
 // the scheduler see what it decided: a batch it refused (n_groups < 0) is not run, and no group beyond its count is.
 void launch_demod(const void *iq0, const void *iq1, uint64_t arena_len, const gr80211_frame_desc *desc, int n,
                   const gr80211_frame_info *info, const void *chan1, const void *chan2, float *llr,
-                  const SchedTotals *totals, hipStream_t s);
+                  const SchedTotals *totals, hipStream_t s, bool axis = false);
 void launch_viterbi(const float *llr, const gr80211_frame_info *info, const int32_t *slot_frame,
                     const GroupInfo *groups, int n_groups, uint32_t *dec, const SchedTotals *totals, hipStream_t s);
 void launch_traceback(const uint32_t *dec, const gr80211_frame_info *info, const int32_t *slot_frame,
@@ -73,7 +73,7 @@ void launch_viterbi_split2(const float *llr, const gr80211_frame_info *info, con
 void launch_decode(const float *llr, const gr80211_frame_info *info, const int32_t *slot_frame,
                    const GroupInfo *groups, int n_groups, uint32_t *dec, uint32_t *bitsw, uint8_t *out, int out_stride,
                    int32_t *out_len, int32_t *n_pdu, uint8_t *bits_out, int bits_stride, int strict,
-                   const SchedTotals *totals, bool large_form, hipStream_t s);
+                   const SchedTotals *totals, bool large_form, hipStream_t s, bool axis = false);
 // Groups a decoder kernel may run: the launch's count, cut to what the scheduler reports on the device.
 __device__ __forceinline__ int groups_to_run(int n_groups, const SchedTotals *totals)
 {

@@ -1098,6 +1098,17 @@ __device__ __forceinline__ void put_llrs(float *stage, c32 q, int mod, float sca
     }
 }
 
+// Experiment (GR80211_AXIS_LLR=1): instead of its soft bits a tone leaves its scaled axis values, one float per
+// constellation axis; every soft bit of an axis is a fold of that one number, which the decoder's tile loader
+// applies (axis_fold).  A symbol then takes nSS * nSD * (1 or 2) floats, tone by tone in the order of the data
+// subcarriers, stream after stream, at a stride of its own in the frame's soft-bit run.
+__device__ __forceinline__ void put_axes(float *stage, c32 q, int mod, float scale, int nb, int slot)
+{
+    if (mod != QAM_BPSK) q = cmulf(q, scale);
+    stage[slot] = q.x;
+    if (nb >= 2) stage[slot + 1] = q.y;
+}
+
 // The wave's staged symbol -> the frame's LLR run, 16 bytes per lane (runs are 16-byte aligned: every frame's
 // soft-bit count is a multiple of 4).  Always P store instructions, whatever the symbol's size: lanes past the
 // end repeat the last four soft bits (the same bytes to the same place).  With a fixed number of stores behind
@@ -1151,7 +1162,8 @@ void k_demod(const c32 *__restrict__ iq0, const c32 *__restrict__ iq1,
                                                             const gr80211_frame_desc *__restrict__ descs, int n,
                                                             const gr80211_frame_info *__restrict__ info,
                                                             const c32 *__restrict__ chan1, const c32 *__restrict__ chan2,
-                                                            float *__restrict__ llr, const SchedTotals *__restrict__ totals)
+                                                            float *__restrict__ llr, const SchedTotals *__restrict__ totals,
+                                                            int axis)
 {
     const int f = blockIdx.x;
     if (f >= n) return;
@@ -1228,6 +1240,12 @@ void k_demod(const c32 *__restrict__ iq0, const c32 *__restrict__ iq1,
             const c32 u = cmulf(cmulf(e, pv), pp);
             const c32 ps = cconj(cadd(cadd(cadd(lane_c<LN7>(u), lane_c<LN21>(u)), lane_c<LN43>(u)), lane_c<LN57>(u)));
             const float pa = cabs32(ps);
+            if (axis) {
+                const int na = nb == 1 ? 1 : 2, nax_sym = (legacy ? 48 : 52) * na;
+                if (jd >= 0) put_axes(stage, cdivf(cmul(e, ps), pa), mod, scale, nb, jd * na);
+                flush_stage<1>(stage, out + (size_t)sym * nax_sym, nax_sym, lane);
+                continue;
+            }
             if (jd >= 0) put_llrs(stage, cdivf(cmul(e, ps), pa), mod, scale, nb, nax, kI, kQ);
             flush_stage<2>(stage, out + (size_t)sym * ncbps, ncbps, lane);
         }
@@ -1284,6 +1302,15 @@ void k_demod(const c32 *__restrict__ iq0, const c32 *__restrict__ iq1,
             acc = cadd(acc, lane_c<LN57>(u2));
             const c32 ps = cconj(acc);
             const float pa = cabs32(ps);
+            if (axis) {
+                const int na = nb == 1 ? 1 : 2, nax_sym = 2 * 52 * na;
+                if (jd >= 0) {
+                    put_axes(stage, cdivf(cmul(s1, ps), pa), mod, scale, nb, jd * na);
+                    put_axes(stage, cdivf(cmul(s2, ps), pa), mod, scale, nb, (52 + jd) * na);
+                }
+                flush_stage<1>(stage, out + (size_t)sym * nax_sym, nax_sym, lane);
+                continue;
+            }
             if (jd >= 0) {
                 put_llrs(stage, cdivf(cmul(s1, ps), pa), mod, scale, nb, nax, kI1, kQ1);
                 put_llrs(stage, cdivf(cmul(s2, ps), pa), mod, scale, nb, nax, kI2, kQ2);
@@ -1435,14 +1462,98 @@ __device__ __forceinline__ void fetch_tile(const float *__restrict__ llr, unsign
     else load_tile(llr, mybase, myn, col0 + lane, tile);
 }
 
+
+// ---- experiment: soft bits folded out of axis values by the tile loader (k_demod's put_axes) ----------------------
+// The modulation every frame of a group shares (wave-uniform).
+struct AxisMod {
+    int nb, ncbps, nss, legacy, didx, nsd, na, nax, sym_floats;
+};
+
+// Column c of a frame's soft-bit stream (decoder order) -> where its axis value lies in the frame's run, and which
+// fold of it the soft bit is: the inverse of the stream de-parser (lib/cloud80211phy.cc:2442-2451), the interleaver
+// (coded bit k is sent at position j = tone * nBPSCS + bit) and the I-bits-then-Q-bits order of a tone.
+__device__ __forceinline__ void axis_map(const AxisMod &m, int c, int &ofs, int &level)
+{
+    const int n = c / m.ncbps, p = c - n * m.ncbps;
+    int iss = 0, k = p;
+    if (m.nss == 2) {
+        const int sblk = m.nb / 2 > 1 ? m.nb / 2 : 1;
+        const int blk = p / sblk;
+        iss = blk & 1;
+        k = (blk >> 1) * sblk + (p - blk * sblk);
+    }
+    const int j = m.legacy ? c_tab.intl_l[m.didx][k] : iss ? c_tab.intl_nl2[m.didx][k] : c_tab.intl_nl[m.didx][k];
+    const int tone = j / m.nb, b = j - tone * m.nb;
+    const int ax = b / m.nax;
+    level = b - ax * m.nax;
+    ofs = n * m.sym_floats + (iss * m.nsd + tone) * m.na + ax;
+}
+
+// Soft bit `level` of an axis whose scaled value is v: axis_llr's operations, one erasure test per axis as in put_llrs.
+__device__ __forceinline__ float axis_fold(float v, int level, int nax)
+{
+    const float edge = nax == 2 ? 2.0f : nax == 3 ? 4.0f : 8.0f;
+    const float o1 = edge - fabsf(v);
+    const float o2 = edge * 0.5f - fabsf(o1);
+    const float o3 = 2.0f - fabsf(o2);
+    const float r = level == 0 ? v : level == 1 ? o1 : level == 2 ? o2 : o3;
+    return __builtin_isfinite(v) ? r : 0.0f;
+}
+
+// The tile whose first column is col0, from axis values.  Inside every frame: one row load per frame as in
+// load_tile_inside, the lane's column offset being where the column's axis value lies; then every lane folds its
+// column, row by row, in LDS.  At the frames' ends (columns clamped per frame) values are loaded and folded one row at
+// a time.
+__device__ __forceinline__ void fetch_tile_axis(const float *__restrict__ llr, unsigned long long mybase, int myn, int least,
+                                                int col0, int lane, lds_float *tile, const AxisMod &m)
+{
+    float *t = (float *)tile;
+    if (col0 + 64 <= least) {
+        int ofs, level;
+        axis_map(m, col0 + lane, ofs, level);
+        const unsigned long long mine = (unsigned long long)(llr + mybase);
+#pragma unroll
+        for (int r = 0; r < 64; r++) {
+            const unsigned lo = __builtin_amdgcn_readlane((int)(mine & 0xffffffffull), r);
+            const unsigned hi = __builtin_amdgcn_readlane((int)(mine >> 32), r);
+            const float *rowp = (const float *)(((unsigned long long)hi << 32) | lo);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(rowp + ofs),
+                                             (__attribute__((address_space(3))) void *)(tile + r * TILE_STRIDE), 4, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        if (m.nax > 1) {
+#pragma unroll 8
+            for (int r = 0; r < 64; r++) t[r * TILE_STRIDE + lane] = axis_fold(t[r * TILE_STRIDE + lane], level, m.nax);
+        }
+    } else {
+        for (int r = 0; r < 64; r++) {
+            const unsigned lo = __builtin_amdgcn_readlane((int)(mybase & 0xffffffffull), r);
+            const unsigned hi = __builtin_amdgcn_readlane((int)(mybase >> 32), r);
+            const int nr = __builtin_amdgcn_readlane(myn, r);
+            const unsigned long long base = ((unsigned long long)hi << 32) | lo;
+            int c = col0 + lane;
+            c = c < nr ? c : nr - 1;
+            c = c < 0 ? 0 : c;
+            int ofs, level;
+            axis_map(m, c, ofs, level);
+            const float v = llr[base + (unsigned long long)ofs];
+            t[r * TILE_STRIDE + lane] = m.nax > 1 ? axis_fold(v, level, m.nax) : (__builtin_isfinite(v) ? v : 0.0f);
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+
 // Forward pass of one group.  TWO_TILES: the wave has room for two tiles in LDS (a batch of at most one group per
 // SIMD) and fetches the next chunk's soft bits while it works on this one; a wave that shares its SIMD leaves the
 // fetch latency to its partner instead.
 // Chunks [ch0, ch1) of a group's forward pass: A holds the path metrics before chunk ch0 on entry and after chunk
 // ch1 - 1 on return (a chunk is an even number of steps, so the metrics end where they started).
-template <int CR, bool TWO_TILES>
+template <int CR, bool TWO_TILES, bool AXIS = false>
 __device__ __forceinline__ void viterbi_chunks(float (&A)[64], const float *__restrict__ llr, unsigned long long mybase, int myn,
-                                               int ch0, int ch1, uint32_t *__restrict__ dec, float *tile, int lane)
+                                               int ch0, int ch1, uint32_t *__restrict__ dec, float *tile, int lane,
+                                               const AxisMod *am = nullptr)
 {
     constexpr int P = Rate<CR>::P, COLS = Rate<CR>::COLS, NPER = Rate<CR>::NPER;
     constexpr int CH = COLS * NPER;    // LLR columns per tile
@@ -1483,8 +1594,12 @@ __device__ __forceinline__ void viterbi_chunks(float (&A)[64], const float *__re
             // the tile belongs to this wave alone: its reads of the previous chunk have returned (their values were
             // used), so the loads below may overwrite it
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            fetch_tile(llr, mybase, myn, least, ch * CH, lane, lt);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if constexpr (AXIS) {
+                fetch_tile_axis(llr, mybase, myn, least, ch * CH, lane, lt, *am);
+            } else {
+                fetch_tile(llr, mybase, myn, least, ch * CH, lane, lt);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
         }
         __builtin_amdgcn_wave_barrier();
         const float *row = cur + lane * TILE_STRIDE;
@@ -1496,14 +1611,15 @@ __device__ __forceinline__ void viterbi_chunks(float (&A)[64], const float *__re
 }
 
 // Forward pass of one group from its first chunk to its last.
-template <int CR, bool TWO_TILES>
+template <int CR, bool TWO_TILES, bool AXIS = false>
 __device__ __forceinline__ void viterbi_group(const float *__restrict__ llr, unsigned long long mybase, int myn,
-                                              int nchunks, uint32_t *__restrict__ dec, float *tile, int lane)
+                                              int nchunks, uint32_t *__restrict__ dec, float *tile, int lane,
+                                              const AxisMod *am = nullptr)
 {
     float A[64];
 #pragma unroll
     for (int i = 0; i < 64; i++) A[i] = i == 0 ? 0.0f : NEG_INIT;
-    viterbi_chunks<CR, TWO_TILES>(A, llr, mybase, myn, 0, nchunks, dec, tile, lane);
+    viterbi_chunks<CR, TWO_TILES, AXIS>(A, llr, mybase, myn, 0, nchunks, dec, tile, lane, am);
 }
 
 __global__ __launch_bounds__(64) void k_viterbi(const float *__restrict__ llr, const gr80211_frame_info *__restrict__ info,
@@ -1666,7 +1782,7 @@ int read_timeline(unsigned long long *dst, int n_groups)
 // 1563 groups: 12.0 against 12.5 ms).
 constexpr int DEC_WAVES = 4;
 
-template <bool TWO_TILES, int WAVES>
+template <bool TWO_TILES, int WAVES, bool AXIS = false>
 __device__ __forceinline__ void decode_wave(const float *__restrict__ llr, const gr80211_frame_info *__restrict__ info,
                                             const int32_t *__restrict__ slot_frame,
                                             const GroupInfo *__restrict__ groups, int n_groups,
@@ -1696,11 +1812,29 @@ __device__ __forceinline__ void decode_wave(const float *__restrict__ llr, const
     const int myn = fr >= 0 ? info[fr].total : 0;
     const unsigned long long mybase = myn > 0 ? (unsigned long long)info[fr].llr_off : 0ull;
     uint32_t *d = dec + gi.dec_off;
+    AxisMod am = {};
+    if constexpr (AXIS) {
+        // every frame of the group must share one modulation: a group that does not is left undecoded
+        const int key = fr >= 0 ? (info[fr].nBPSCS | (info[fr].nCBPS << 4) | (info[fr].nSS << 16) | ((info[fr].format == GR80211_F_L) << 20)) : -1;
+        int first = key;
+        for (int dd = 32; dd > 0; dd >>= 1) { const int o = __shfl_xor(first, dd); first = first > o ? first : o; }
+        first = __builtin_amdgcn_readfirstlane(first);
+        if (__builtin_amdgcn_ballot_w64(key >= 0 && key != first) != 0) return;
+        am.nb = first & 15;
+        am.ncbps = (first >> 4) & 0xfff;
+        am.nss = (first >> 16) & 15;
+        am.legacy = (first >> 20) & 1;
+        am.didx = am.nb == 1 ? 0 : am.nb == 2 ? 1 : am.nb == 4 ? 2 : am.nb == 6 ? 3 : 4;
+        am.nsd = am.legacy ? 48 : 52;
+        am.na = am.nb == 1 ? 1 : 2;
+        am.nax = am.nb == 1 ? 1 : am.nb / 2;
+        am.sym_floats = am.nss * am.nsd * am.na;
+    }
     switch (gi.cr) {
-    case CR_12: viterbi_group<CR_12, TWO_TILES>(llr, mybase, myn, gi.nchunks, d, tile, lane); break;
-    case CR_23: viterbi_group<CR_23, TWO_TILES>(llr, mybase, myn, gi.nchunks, d, tile, lane); break;
-    case CR_34: viterbi_group<CR_34, TWO_TILES>(llr, mybase, myn, gi.nchunks, d, tile, lane); break;
-    default: viterbi_group<CR_56, TWO_TILES>(llr, mybase, myn, gi.nchunks, d, tile, lane); break;
+    case CR_12: viterbi_group<CR_12, TWO_TILES, AXIS>(llr, mybase, myn, gi.nchunks, d, tile, lane, &am); break;
+    case CR_23: viterbi_group<CR_23, TWO_TILES, AXIS>(llr, mybase, myn, gi.nchunks, d, tile, lane, &am); break;
+    case CR_34: viterbi_group<CR_34, TWO_TILES, AXIS>(llr, mybase, myn, gi.nchunks, d, tile, lane, &am); break;
+    default: viterbi_group<CR_56, TWO_TILES, AXIS>(llr, mybase, myn, gi.nchunks, d, tile, lane, &am); break;
     }
     // every lane reads back only survivor words it stored itself; drain the stores first
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1742,6 +1876,18 @@ void k_decode_lean(const float *__restrict__ llr, const gr80211_frame_info *__re
 {
     decode_wave<false, 1>(llr, info, slot_frame, groups, n_groups, dec, bitsw, out, out_stride, out_len, n_pdu, bits_out,
                           bits_stride, strict, totals);
+}
+
+// The same with the tile loader that folds soft bits out of axis values (experiment, GR80211_AXIS_LLR=1).
+__global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(108)))
+void k_decode_lean_axis(const float *__restrict__ llr, const gr80211_frame_info *__restrict__ info,
+                        const int32_t *__restrict__ slot_frame, const GroupInfo *__restrict__ groups, int n_groups,
+                        uint32_t *__restrict__ dec, uint32_t *__restrict__ bitsw, uint8_t *__restrict__ out, int out_stride,
+                        int32_t *__restrict__ out_len, int32_t *__restrict__ n_pdu, uint8_t *__restrict__ bits_out,
+                        int bits_stride, int strict, const SchedTotals *__restrict__ totals)
+{
+    decode_wave<false, 1, true>(llr, info, slot_frame, groups, n_groups, dec, bitsw, out, out_stride, out_len, n_pdu, bits_out,
+                                bits_stride, strict, totals);
 }
 
 // =========================================================================================
@@ -1943,14 +2089,14 @@ void launch_schedule(gr80211_frame_info *info, int n, int assign_llr, int32_t *s
 }
 void launch_demod(const void *iq0, const void *iq1, uint64_t arena_len, const gr80211_frame_desc *desc, int n,
                   const gr80211_frame_info *info, const void *chan1, const void *chan2, float *llr,
-                  const SchedTotals *totals, hipStream_t s)
+                  const SchedTotals *totals, hipStream_t s, bool axis)
 {
     hipLaunchKernelGGL(k_demod<1>, dim3(n), dim3(256), 0, s, (const c32 *)iq0, (const c32 *)iq1, arena_len, desc, n, info,
-                       (const c32 *)chan1, (const c32 *)chan2, llr, totals);
+                       (const c32 *)chan1, (const c32 *)chan2, llr, totals, axis ? 1 : 0);
     // two-stream frames only exist where a second antenna does
     if (iq1)
         hipLaunchKernelGGL(k_demod<2>, dim3(n), dim3(256), 0, s, (const c32 *)iq0, (const c32 *)iq1, arena_len, desc, n,
-                           info, (const c32 *)chan1, (const c32 *)chan2, llr, totals);
+                           info, (const c32 *)chan1, (const c32 *)chan2, llr, totals, axis ? 1 : 0);
 }
 void launch_viterbi(const float *llr, const gr80211_frame_info *info, const int32_t *slot_frame,
                     const GroupInfo *groups, int n_groups, uint32_t *dec, const SchedTotals *totals, hipStream_t s)
@@ -1968,8 +2114,13 @@ void launch_traceback(const uint32_t *dec, const gr80211_frame_info *info, const
 void launch_decode(const float *llr, const gr80211_frame_info *info, const int32_t *slot_frame,
                    const GroupInfo *groups, int n_groups, uint32_t *dec, uint32_t *bitsw, uint8_t *out, int out_stride,
                    int32_t *out_len, int32_t *n_pdu, uint8_t *bits_out, int bits_stride, int strict,
-                   const SchedTotals *totals, bool large_form, hipStream_t s)
+                   const SchedTotals *totals, bool large_form, hipStream_t s, bool axis)
 {
+    if (axis) {
+        hipLaunchKernelGGL(k_decode_lean_axis, dim3(n_groups), dim3(64), 0, s, llr, info, slot_frame, groups, n_groups, dec,
+                           bitsw, out, out_stride, out_len, n_pdu, bits_out, bits_stride, strict, totals);
+        return;
+    }
     // A batch of at most one group per SIMD runs fastest with exactly one wave on every SIMD (a lone wave finishes
     // its trellis in three quarters of the time a paired one needs): workgroups of four waves with two LDS tiles each,
     // 130 KB per workgroup, so a CU takes one workgroup and 256 workgroups cover the 256 CUs.  Larger batches run one

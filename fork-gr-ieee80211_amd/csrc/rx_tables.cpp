@@ -46,7 +46,10 @@ void build_tables(Tables &t)
     const int nb_l[4] = {1, 2, 4, 6};
     for (int m = 0; m < 4; m++) {
         const int n = 48 * nb_l[m];
-        for (int k = 0; k < n; k++) t.deint_l[m][interleave_pos(k, n, nb_l[m], 16)] = (int16_t)k;
+        for (int k = 0; k < n; k++) {
+            t.deint_l[m][interleave_pos(k, n, nb_l[m], 16)] = (int16_t)k;
+            t.intl_l[m][k] = (int16_t)interleave_pos(k, n, nb_l[m], 16);
+        }
     }
     const int nb_n[5] = {1, 2, 4, 6, 8};
     for (int m = 0; m < 5; m++) {
@@ -56,6 +59,8 @@ void build_tables(Tables &t)
             t.deint_nl[m][j] = (int16_t)k;
             const int r = ((j - 2 * 11 * nb_n[m]) % n + n) % n;  // third permutation, stream 2
             t.deint_nl2[m][r] = (int16_t)k;
+            t.intl_nl[m][k] = (int16_t)j;
+            t.intl_nl2[m][k] = (int16_t)r;
         }
     }
     for (int i = 0; i < 64; i++) {

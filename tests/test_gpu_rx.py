@@ -954,3 +954,25 @@ def test_six_contexts_on_a_pool_of_three_work_sets(pkg):
     finally:
         for c in ctxs + [ref]:
             c.close()
+
+
+def test_axis_value_soft_bits_give_the_same_bytes(pkg):
+    """The experimental soft-bit layout (GR80211_AXIS_LLR=1: one float per constellation axis from the demodulator, folded
+    into soft bits by the decoder's tile loader) against the default path on batches of one modulation and many lengths:
+    the same PDU bytes, lengths and counts for every modulation family and both stream counts."""
+    import os
+    import sys
+    import torch
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import axis_parity
+    saved = {k: os.environ.get(k) for k in ("GR80211_GROUP_WAVES", "GR80211_AXIS_LLR")}
+    try:
+        bad = axis_parity.compare(torch, pkg, [(0, 0, 1), (0, 5, 1), (1, 7, 1), (1, 11, 2), (2, 8, 1), (2, 4, 2), (2, 8, 2)],
+                                  snr0s=(12.0,), n=200)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    assert bad == 0
