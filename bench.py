@@ -463,6 +463,8 @@ class Rotation:
         self.ctxs = [first_ctx] + [pkg.RxContext(local) for _ in range(pipe - 1)]
         for c in self.ctxs:
             c.use_work_pool(pool)
+            # several batches in flight: the decoder forms with the fewest instructions per frame, whatever the batch size
+            c.set_lane_state_max(0 if pipe > 1 else -1)
         self.outs = [(torch.zeros((n, out_stride), dtype=torch.uint8, device=dev),
                       torch.zeros(n, dtype=torch.int32, device=dev),
                       torch.zeros(n, dtype=torch.int32, device=dev)) for _ in range(self.depth)]
@@ -581,7 +583,8 @@ def main():
                          "thread each; N = 1 only; 1 = skip)")
     ap.add_argument("--pool", type=int, default=-1,
                     help="work sets (soft bits, survivor words, decoded bits) the rotating contexts share "
-                         "(gr80211_use_work_pool); 0 = every context its own; -1 = three when more than three contexts rotate")
+                         "(gr80211_use_work_pool); 0 = every context its own; -1 = three when more than three contexts rotate "
+                         "and their own buffers would take more than 48 GB together")
     ap.add_argument("--latency", type=int, default=1, help="also time small batches one at a time (0 = skip)")
     ap.add_argument("--force-collective", action="store_true",
                     help="N = 1: run the exchange step all the same (process group of one rank, the gather of the MPDUs on "
@@ -663,7 +666,22 @@ def main():
     queues = int(os.environ.get("GPU_MAX_HW_QUEUES", "4") or 4)
     pipe = args.pipeline if args.pipeline > 0 else (6 if queues >= 8 else 3 if not collective else 2)
     compact = args.gather == "compact" or (args.gather == "auto" and args.workload in (MIXED, CAPTURE))
-    pool = args.pool if args.pool >= 0 else (3 if pipe > 3 else 0)
+    if args.pool >= 0:
+        pool = args.pool
+    elif pipe <= 3:
+        pool = 0
+    else:
+        # what one context's work buffers take for this batch decides: six sets of a small batch are cheap and let six
+        # batches overlap, six of the headline batch would hold 100 GB
+        probe = pkg.RxContext(local)
+        for a0, a1, d_, npart, _, _ in parts:
+            probe.rx_batch(a0, a1, d_, npart, out_stride=out_stride, want_info=False)
+        probe.sync()
+        own_bytes = probe.work_memory()[0]
+        probe.close()
+        del probe
+        torch.cuda.empty_cache()
+        pool = 3 if own_bytes * pipe > 48e9 else 0
     rot = Rotation(torch, dist, pkg, shard, local, dev, parts, n, out_stride, pipe, collective, compact, ctx,
                    side_copy=args.side_copy and not collective, pool=pool)
     out, out_len, n_pdu = rot.outs[0]
@@ -734,6 +752,7 @@ def main():
     serial_ms = None
     if pipe > 1:
         rot.fence(collective)
+        rot.ctxs[0].set_lane_state_max(-1)  # a batch alone: small ones take the form that gets them done soonest
         t1 = time.perf_counter()
         with torch.cuda.stream(rot.streams[0]):
             for _ in range(args.steps):
@@ -752,6 +771,8 @@ def main():
             import threading
             depth_f = args.in_flight
             fctxs = rot.ctxs[:depth_f] + [pkg.RxContext(local) for _ in range(depth_f - len(rot.ctxs[:depth_f]))]
+            for c in fctxs:
+                c.set_lane_state_max(0)
             fouts = [(out, out_len, n_pdu)] + [tuple(torch.zeros_like(t) for t in (out, out_len, n_pdu))
                                                 for _ in range(depth_f - 1)]
             errors = []
@@ -797,6 +818,7 @@ def main():
 
     # ---- per-kernel durations from HIP events on the launch stream (untimed extra steps)
     timing = {}
+    ctx.set_lane_state_max(-1)  # from here on one batch at a time
     if args.profile_steps > 0 and len(parts) == 1:
         ctx.set_profiling(True)
         acc = {}

@@ -100,7 +100,8 @@ struct gr80211_ctx {
                                 // wavefront per frame (lane = trellis state)
     bool axis_llr = false;      // GR80211_AXIS_LLR=1 (experiment): the demodulator leaves one value per constellation axis, the
                                 // one-wave decoder folds the soft bits out of it; batches of one modulation per group only
-    int lane_state_max = 14000;  // batches of at most this many frames take the one-wavefront-per-frame form
+    int lane_state_max = 14000;
+    int lane_state_default = 14000;  // what gr80211_set_lane_state_max(-1) goes back to (GR80211_LANE_STATE_MAX)  // batches of at most this many frames take the one-wavefront-per-frame form
                                 // (GR80211_LANE_STATE_MAX; 0 switches the form off)
     hipEvent_t ev[7] = {};
     float ms[6] = {};
@@ -816,7 +817,7 @@ int gr80211_create(gr80211_ctx **out, int device)
     c->device = device;
     if (const char *e = getenv("GR80211_SPLIT_DECODE")) c->split_decode = e[0] == '1';
     if (const char *e = getenv("GR80211_GROUP_WAVES")) c->group_waves = atoi(e);
-    if (const char *e = getenv("GR80211_LANE_STATE_MAX")) c->lane_state_max = atoi(e);
+    if (const char *e = getenv("GR80211_LANE_STATE_MAX")) c->lane_state_max = c->lane_state_default = atoi(e);
     if (const char *e = getenv("GR80211_AXIS_LLR")) c->axis_llr = e[0] == '1';
     if (const char *e = getenv("GR80211_WORK_POOL")) {
         const int sets = atoi(e);
@@ -1735,6 +1736,13 @@ int gr80211_set_ampdu_strict(gr80211_ctx *c, int on)
 {
     if (!c) return GR80211_ERR_ARG;
     c->ampdu_strict = on != 0;
+    return GR80211_OK;
+}
+
+int gr80211_set_lane_state_max(gr80211_ctx *c, int max_frames)
+{
+    if (!c) return GR80211_ERR_ARG;
+    c->lane_state_max = max_frames < 0 ? c->lane_state_default : max_frames;
     return GR80211_OK;
 }
 

@@ -1155,15 +1155,14 @@ __device__ __forceinline__ c32 derot(int k, float rad)
 // 2x2 channel matrices).  At most 96 registers per lane (the attribute counts in pairs on this target): five waves
 // of the two-stream form per SIMD instead of four (103 registers without it; four values spilled), which this
 // latency-bound kernel turns into 1.29 -> 1.10 ms at 50 000 two-stream frames; the one-stream form needs 67 anyway.
-template <int NSS>
+template <int NSS, bool AXIS>
 __global__ __launch_bounds__(64 * DEMOD_WAVES) __attribute__((amdgpu_num_vgpr(48)))
 void k_demod(const c32 *__restrict__ iq0, const c32 *__restrict__ iq1,
                                                             uint64_t arena_len,
                                                             const gr80211_frame_desc *__restrict__ descs, int n,
                                                             const gr80211_frame_info *__restrict__ info,
                                                             const c32 *__restrict__ chan1, const c32 *__restrict__ chan2,
-                                                            float *__restrict__ llr, const SchedTotals *__restrict__ totals,
-                                                            int axis)
+                                                            float *__restrict__ llr, const SchedTotals *__restrict__ totals)
 {
     const int f = blockIdx.x;
     if (f >= n) return;
@@ -1240,7 +1239,7 @@ void k_demod(const c32 *__restrict__ iq0, const c32 *__restrict__ iq1,
             const c32 u = cmulf(cmulf(e, pv), pp);
             const c32 ps = cconj(cadd(cadd(cadd(lane_c<LN7>(u), lane_c<LN21>(u)), lane_c<LN43>(u)), lane_c<LN57>(u)));
             const float pa = cabs32(ps);
-            if (axis) {
+            if constexpr (AXIS) {
                 const int na = nb == 1 ? 1 : 2, nax_sym = (legacy ? 48 : 52) * na;
                 if (jd >= 0) put_axes(stage, cdivf(cmul(e, ps), pa), mod, scale, nb, jd * na);
                 flush_stage<1>(stage, out + (size_t)sym * nax_sym, nax_sym, lane);
@@ -1302,7 +1301,7 @@ void k_demod(const c32 *__restrict__ iq0, const c32 *__restrict__ iq1,
             acc = cadd(acc, lane_c<LN57>(u2));
             const c32 ps = cconj(acc);
             const float pa = cabs32(ps);
-            if (axis) {
+            if constexpr (AXIS) {
                 const int na = nb == 1 ? 1 : 2, nax_sym = 2 * 52 * na;
                 if (jd >= 0) {
                     put_axes(stage, cdivf(cmul(s1, ps), pa), mod, scale, nb, jd * na);
@@ -2091,12 +2090,20 @@ void launch_demod(const void *iq0, const void *iq1, uint64_t arena_len, const gr
                   const gr80211_frame_info *info, const void *chan1, const void *chan2, float *llr,
                   const SchedTotals *totals, hipStream_t s, bool axis)
 {
-    hipLaunchKernelGGL(k_demod<1>, dim3(n), dim3(256), 0, s, (const c32 *)iq0, (const c32 *)iq1, arena_len, desc, n, info,
-                       (const c32 *)chan1, (const c32 *)chan2, llr, totals, axis ? 1 : 0);
+    if (axis) {
+        hipLaunchKernelGGL((k_demod<1, true>), dim3(n), dim3(256), 0, s, (const c32 *)iq0, (const c32 *)iq1, arena_len, desc, n,
+                           info, (const c32 *)chan1, (const c32 *)chan2, llr, totals);
+        if (iq1)
+            hipLaunchKernelGGL((k_demod<2, true>), dim3(n), dim3(256), 0, s, (const c32 *)iq0, (const c32 *)iq1, arena_len,
+                               desc, n, info, (const c32 *)chan1, (const c32 *)chan2, llr, totals);
+        return;
+    }
+    hipLaunchKernelGGL((k_demod<1, false>), dim3(n), dim3(256), 0, s, (const c32 *)iq0, (const c32 *)iq1, arena_len, desc, n,
+                       info, (const c32 *)chan1, (const c32 *)chan2, llr, totals);
     // two-stream frames only exist where a second antenna does
     if (iq1)
-        hipLaunchKernelGGL(k_demod<2>, dim3(n), dim3(256), 0, s, (const c32 *)iq0, (const c32 *)iq1, arena_len, desc, n,
-                           info, (const c32 *)chan1, (const c32 *)chan2, llr, totals, axis ? 1 : 0);
+        hipLaunchKernelGGL((k_demod<2, false>), dim3(n), dim3(256), 0, s, (const c32 *)iq0, (const c32 *)iq1, arena_len, desc,
+                           n, info, (const c32 *)chan1, (const c32 *)chan2, llr, totals);
 }
 void launch_viterbi(const float *llr, const gr80211_frame_info *info, const int32_t *slot_frame,
                     const GroupInfo *groups, int n_groups, uint32_t *dec, const SchedTotals *totals, hipStream_t s)

@@ -1451,6 +1451,9 @@ demod::demod(int n_rx, int mupos, int batch_frames, int device)
 
 demod::~demod()
 {
+    if (getenv("GR80211_BLOCK_PROFILE"))
+        fprintf(stderr, "demod block: %llu frames, %llu rounds; host seconds: harvest %.4f tags %.4f copy in %.4f soft bits out %.4f other %.4f\n",
+                (unsigned long long)d_nSeen, (unsigned long long)d_nRounds, d_tHarvest, d_tTags, d_tCopyIn, d_tPop, d_tOther);
     for (auto &r : d_round) {
         if (r->worker.joinable()) r->worker.join();
         for (int a = 0; a < 2; a++)
@@ -1504,7 +1507,13 @@ int demod::general_work(int noutput_items, gr_vector_int &ninput_items, gr_vecto
 {
     int n = ninput_items[0];
     if (d_nrx == 2) n = std::min(n, ninput_items[1]);
-    if (!harvest(false)) {
+    static const bool prof = getenv("GR80211_BLOCK_PROFILE") != nullptr;
+    auto now = [] { return prof ? std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() : 0.0; };
+    double t0 = now();
+    auto lap = [&](double &acc) { if (prof) { const double t = now(); acc += t - t0; t0 = t; } };
+    const bool harvested = harvest(false);
+    lap(d_tHarvest);
+    if (!harvested) {
         consume_each(0);
         return 0;
     }
@@ -1534,6 +1543,7 @@ int demod::general_work(int noutput_items, gr_vector_int &ninput_items, gr_vecto
                 used = (int)(tags[0].offset - nitems_read(0));
                 continue;
             }
+            lap(d_tOther);
             gr80211_sig_desc d;
             memset(&d, 0, sizeof(d));
             d.off = r.n;
@@ -1556,6 +1566,7 @@ int demod::general_work(int noutput_items, gr_vector_int &ninput_items, gr_vecto
             d_need = d.nsamp;
             d_skip = 320;  // lib/demod_impl.cc:92
             d_state = S_COLLECT;
+            lap(d_tTags);
         }
         if (d_state == S_COLLECT) {
             const int take = (int)std::min<long>(d_need, n - used);
@@ -1566,6 +1577,7 @@ int demod::general_work(int noutput_items, gr_vector_int &ninput_items, gr_vecto
             for (int a = 0; a < d_nrx; a++)
                 memcpy(r.iq[a] + r.n, static_cast<const gr_complex *>(input_items[(size_t)a]) + used, (size_t)take * sizeof(gr_complex));
             r.n += (size_t)take;
+            lap(d_tCopyIn);
             r.desc.back().n_avail += (uint32_t)take;
             d_need -= take;
             used += take;
@@ -1587,7 +1599,9 @@ int demod::general_work(int noutput_items, gr_vector_int &ninput_items, gr_vecto
     consume_each(used);
     if (output_items.empty()) return 0;
     tags.clear();
+    lap(d_tOther);
     int produced = d_out.pop(output_items[0], noutput_items, nitems_written(0), tags);
+    lap(d_tPop);
     if (used == 0 && produced == 0 && n > 0 && noutput_items > 0 && !d_flight.empty()) {
         // Neither input taken (every round is on its way) nor output to give: the one case in which the call waits,
         // for the oldest round, so that a caller never sees a call without progress while work is in flight (a

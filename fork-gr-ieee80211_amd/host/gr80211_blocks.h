@@ -538,6 +538,7 @@ private:
     long d_need = 0, d_skip = 0;            // items of the current frame still to collect / to pass over
     out_stream d_out;
     uint64_t d_nSeen = 0, d_nRounds = 0;
+    double d_tHarvest = 0, d_tTags = 0, d_tCopyIn = 0, d_tPop = 0, d_tOther = 0;  // GR80211_BLOCK_PROFILE: where the host time goes
 };
 
 // Whole receive flowgraph of examples/rx.grc / rx2.grc: inputs are the antenna streams only ({c64} or {c64, c64});

@@ -70,7 +70,7 @@ EXPORTS = [
     "gr80211_create", "gr80211_destroy", "gr80211_last_error", "gr80211_sync", "gr80211_rx_batch", "gr80211_signal_batch", "gr80211_detect", "gr80211_rx_capture",
     "gr80211_demod_batch", "gr80211_decode_batch", "gr80211_dev_alloc", "gr80211_dev_free",
     "gr80211_copy_h2d", "gr80211_copy_d2h", "gr80211_set_profiling", "gr80211_last_timing",
-    "gr80211_version", "gr80211_table_checksum", "gr80211_tx_samples", "gr80211_tx_batch", "gr80211_set_mu_pos", "gr80211_set_ampdu_strict", "gr80211_tx_mu_batch",
+    "gr80211_version", "gr80211_table_checksum", "gr80211_tx_samples", "gr80211_tx_batch", "gr80211_set_mu_pos", "gr80211_set_ampdu_strict", "gr80211_set_lane_state_max", "gr80211_tx_mu_batch",
     "gr80211_host_alloc", "gr80211_host_free", "gr80211_copy_d2d", "gr80211_signal_emit_batch", "gr80211_demod_tagged_batch",
     "gr80211_rx_submit", "gr80211_rx_finish", "gr80211_decode_batch_noalloc", "gr80211_rx_resume",
     "gr80211_last_batch_refused", "gr80211_copy_h2d_async", "gr80211_copy_d2h_async", "gr80211_copy_d2d_async", "gr80211_pull_h2d", "gr80211_pull_done", "gr80211_push_d2h", "gr80211_get_stream",
@@ -146,6 +146,7 @@ def load_library():
     L.gr80211_use_work_pool.argtypes = [vp, C.c_int]
     L.gr80211_work_memory.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_int)]
     L.gr80211_set_ampdu_strict.argtypes = [vp, C.c_int]
+    L.gr80211_set_lane_state_max.argtypes = [vp, C.c_int]
     L.gr80211_last_timing.argtypes = [vp, C.POINTER(C.c_float), C.c_int]
     L.gr80211_tx_samples.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
     L.gr80211_tx_batch.argtypes = [vp, vp, C.c_uint64, vp, C.c_int, C.c_uint, vp, vp, C.c_uint64, vp, vp]
@@ -241,6 +242,11 @@ class RxContext:
 
     def set_ampdu_strict(self, on):
         self._check(self.lib.gr80211_set_ampdu_strict(self.h, 1 if on else 0), "set_ampdu_strict")
+
+    def set_lane_state_max(self, max_frames):
+        """Batches of at most max_frames frames take the one-frame-per-wave decoder (lowest latency alone); 0 = never,
+        for callers that keep several batches in flight; < 0 = the default."""
+        self._check(self.lib.gr80211_set_lane_state_max(self.h, int(max_frames)), "set_lane_state_max")
 
     def last_timing(self):
         ms = (C.c_float * 6)()

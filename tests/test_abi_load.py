@@ -159,8 +159,8 @@ def test_large_batch_decoder_leaves_register_room(pkg, tmp_path):
             if "\n    .name:" in m.group(2):
                 continue  # ran into the next kernel's record
             found[m.group(1)] = int(m.group(3))
-    lean = [v for k, v in found.items() if "k_decode_lean" in k]
-    demod = [v for k, v in found.items() if "k_demodILi1E" in k]
+    lean = [v for k, v in found.items() if "k_decode_leanE" in k]
+    demod = [v for k, v in found.items() if "k_demodILi1ELb0E" in k]
     pre = [v for k, v in found.items() if "k_preamble" in k]
     assert len(lean) == 1 and len(demod) == 1 and len(pre) == 1, sorted(found)
     gran = 8  # registers are handed out in blocks of eight

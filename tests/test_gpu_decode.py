@@ -251,6 +251,38 @@ def test_group_widths_agree_bit_for_bit(pkg, ctx_by_waves):
         assert np.array_equal(got[1][0][valid], got[w][0][valid]), w
 
 
+def test_small_batch_form_is_the_callers_choice(pkg):
+    """gr80211_set_lane_state_max moves the batch size up to which the one-frame-per-wave decoder is taken: the same
+    small batch with the default, with the form switched off and with the default again gives the same bytes."""
+    import torch
+    tx = pkg.txgen
+    rx = pkg.rx
+    rng = np.random.default_rng(3)
+    frames = [coded_frame(tx, rng, (0, 1, 2)[k % 3], k % 4, int(rng.integers(30, 900)), mcs=k % 8, snr_scale=1.6, noise=0.9)
+              for k in range(150)]
+    desc = np.zeros(len(frames), dtype=rx.DEC_DESC_DTYPE)
+    off = 0
+    for i, f in enumerate(frames):
+        desc[i] = (off, len(f["llr"]), f["fmt"], f["len"], f["cr"], f["mcs"], f["ampdu"], f["trellis"], 0)
+        off += len(f["llr"])
+    llr = torch.from_numpy(np.concatenate([f["llr"] for f in frames])).cuda()
+    c = pkg.RxContext(0)
+    try:
+        got = []
+        for limit in (-1, 0, 100, -1):   # 100 < 150 frames: the limit counts frames
+            c.set_lane_state_max(limit)
+            r = c.decode_batch(llr, desc, len(frames), out_stride=1024)
+            c.sync()
+            ol = r["out_len"].cpu().numpy()
+            valid = np.arange(1024)[None, :] < ol[:, None]
+            got.append((ol, r["n_pdu"].cpu().numpy(), r["out"].cpu().numpy() * valid))
+        assert 0 < int(got[0][1].sum())
+        for g in got[1:]:
+            assert all(np.array_equal(a, b) for a, b in zip(got[0], g))
+    finally:
+        c.close()
+
+
 def test_reference_bit_vector_decodes_to_reference_packet(pkg, ctx_by_waves):
     """The interleaved coded bits the reference keeps for its example packet (tools/txbits.py, HT MCS0), put
     through its own deinterleaver map as hard soft bits: both decoder forms must return the packet its IQ

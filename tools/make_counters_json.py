@@ -12,7 +12,7 @@ import os
 import re
 import sys
 
-KERNELS = {"k_decode": "k_decode(?:_lean)?", "k_demod": "k_demod", "k_preamble": "k_preamble", "k_viterbi_split": "k_viterbi_split",
+KERNELS = {"k_decode": "k_decode(?:_lean|_split2|_lane_state)?", "k_demod": "k_demod", "k_preamble": "k_preamble", "k_viterbi_split": "k_viterbi_split",
            "k_traceback": "k_traceback", "k_det_ac": "k_det_ac"}
 
 
@@ -35,6 +35,8 @@ def main(d, workload, frames, tag):
                 k = kernel_key(m.group(1))
                 if k and k not in out:
                     out[k] = {"duration_ns": float(m.group(4)), "launches": int(m.group(2))}
+                    if k == "k_decode":  # which of the decoder's forms the batch size selected
+                        out[k]["kernel"] = re.search(r"k_decode\w*(?:<[^>]*>)?", m.group(1)).group(0)
     for fn in sorted(glob.glob(os.path.join(d, "pmc_*.txt"))):
         seen = False
         for line in open(fn):

@@ -70,9 +70,11 @@ def main():
     ns = n * L
     print("%d VHT MCS8 frames, %d samples per antenna, %.0f MB of IQ; %d of them as soft bits, %.0f MB" %
           (n, ns, ns * 8 / 1e6, ns_dec // L, os.path.getsize(f_llr) / 1e6), flush=True)
+    only = os.environ.get("GR80211_STREAM_ONLY", "")  # "chain": the three-block rows alone
     for pin in (True, False):
         for chunk, batch in ((8192, 4096), (65536, 4096), (65536, 16384), (1 << 18, 16384), (1 << 20, 16384)):
-            run(["rx", 1, chunk, batch, f_tr, f_iq], ns, "rx      window %7d batch %5d" % (chunk, batch), pin)
+            if not only:
+                run(["rx", 1, chunk, batch, f_tr, f_iq], ns, "rx      window %7d batch %5d" % (chunk, batch), pin)
     # the reference's three blocks as three blocks: one thread each (a flowgraph), and all on one thread
     n_chain = min(n, 60000)
     f_iqc = f_iq
@@ -90,10 +92,11 @@ def main():
         run(["chain", 1, 65536, 4096, f_trc, f_iqc], n_chain * L, "chain, 1 thread  window   65536 batch  4096")
     for f in (f_trc,) + ((f_iqc,) if f_iqc != f_iq else ()):
         os.remove(f)
-    run(["capture", 1, 65536, f_iq], ns, "capture window   65536")
-    for pin in (True, False):
-        for chunk, batch in ((65536, 4096), (65536, 16384), (1 << 18, 16384), (1 << 20, 16384)):
-            run(["decode", chunk, batch, f_tg, f_llr], ns_dec, "decode  window %7d batch %5d" % (chunk, batch), pin)
+    if not only:
+        run(["capture", 1, 65536, f_iq], ns, "capture window   65536")
+        for pin in (True, False):
+            for chunk, batch in ((65536, 4096), (65536, 16384), (1 << 18, 16384), (1 << 20, 16384)):
+                run(["decode", chunk, batch, f_tg, f_llr], ns_dec, "decode  window %7d batch %5d" % (chunk, batch), pin)
     for f in (f_iq, f_tr, f_llr, f_tg):
         os.remove(f)
 
