@@ -731,6 +731,13 @@ int decode::general_work(int, gr_vector_int &ninput_items, gr_vector_const_void_
                 d.ampdu = (int32_t)t_ampdu;
                 d.trellis = (int32_t)v_trellis;
                 f.desc.push_back(d);
+                if (d_debug) {
+                    // what the reference's debug lines quote beside the counters (lib/decode_impl.cc:383-387)
+                    static const char *const dkeys[5] = {"cfo", "snr", "rssi", "sssnr0", "sssnr1"};
+                    double dv[5] = {0, 0, 0, 0, 0};
+                    tag_values_at(0, at, dkeys, dv, 5);
+                    f.dbg.push_back({(float)dv[0], (float)dv[1], (float)dv[2], (float)dv[3], (float)dv[4]});
+                }
             }
         }
         if (d_state == S_COLLECT || d_state == S_CLEAN) {
@@ -806,6 +813,37 @@ void decode::publish_ready(round &r, size_t upto_desc, size_t &at)
     for (; at < r.ready.size() && r.ready[at].first <= upto_desc; at++) message_port_pub("out", r.ready[at].second);
 }
 
+// The per-MCS counters of packets with a good FCS that the reference prints when made with ifdebug
+// (lib/decode_impl.cc:375-411,453-509; scraped by its tools/performance scripts: last line with "crc32" and the format's
+// name, fields 3 ... 3 + nMcs).  One "correct" line per MPDU published, one "wrong" line for a packet that published
+// none (the reference prints one per failed subframe of a VHT A-MPDU; the GPU returns the good ones only).  Aggregated HT
+// packets print nothing there and nothing here.
+void decode::debug_lines(const gr80211_dec_desc &d, const debug_tags &t, uint64_t n_pub)
+{
+    const bool vht = d.format == 2, legacy = d.format == 0;
+    if (!vht && d.ampdu) return;
+    const uint64_t lines = n_pub ? n_pub : 1;
+    for (uint64_t k = 0; k < lines; k++) {
+        if (n_pub) {
+            d_nPktCorrect++;
+            if (vht) {
+                if (d.mcs >= 0 && d.mcs < 10) d_vhtMcsCount[d.mcs]++;
+            } else if (legacy) {
+                if (d.mcs >= 0 && d.mcs < 8) d_legacyMcsCount[d.mcs]++;
+            } else if (d.mcs >= 0) {
+                d_htMcsCount[d.mcs % 8]++;
+            }
+        }
+        std::string line = std::string("ieee80211 decode, ") + (vht ? "vht" : legacy ? "legacy" : "ht") + " crc32 " +
+                           (n_pub ? "correct" : "wrong") + ", total:" + std::to_string(d_nPktCorrect);
+        const uint64_t *cnt = vht ? d_vhtMcsCount : legacy ? d_legacyMcsCount : d_htMcsCount;
+        for (int i = 0; i < (vht ? 10 : 8); i++) line += "," + std::to_string(i) + ":" + std::to_string(cnt[i]);
+        line += ",cfo:" + std::to_string(t.cfo) + ",snr:" + std::to_string(t.snr) + ",rssi:" + std::to_string(t.rssi);
+        if (vht) line += ",sssnr0:" + std::to_string(t.sssnr0) + ",sssnr1:" + std::to_string(t.sssnr1);
+        fprintf(d_debugOut ? d_debugOut : stdout, "%s\n", line.c_str());
+    }
+}
+
 // The oldest rounds in flight are published as their streams run dry.  wait_front: wait for the oldest one;
 // wait_all: for all.
 bool decode::advance(bool wait_front, bool wait_all)
@@ -829,11 +867,14 @@ bool decode::advance(bool wait_front, bool wait_all)
         size_t at = 0;
         for (int i = 0; i < nf; i++) {
             publish_ready(*r, (size_t)i, at);
-            d_nPdu += publish_slots(out + (size_t)i * OUT_STRIDE, len + i, 1, OUT_STRIDE);
+            const uint64_t np = publish_slots(out + (size_t)i * OUT_STRIDE, len + i, 1, OUT_STRIDE);
+            d_nPdu += np;
+            if (d_debug && (size_t)i < r->dbg.size()) debug_lines(r->desc[(size_t)i], r->dbg[(size_t)i], np);
         }
         publish_ready(*r, (size_t)nf, at);
         r->ready.clear();
         r->desc.clear();
+        r->dbg.clear();
         r->n = 0;
         r->state = round::FREE;
         d_flight.pop_front();

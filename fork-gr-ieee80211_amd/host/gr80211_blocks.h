@@ -20,6 +20,7 @@
 #pragma once
 
 #include <chrono>
+#include <cstdio>
 #include <complex>
 #include <cstdint>
 #include <deque>
@@ -304,6 +305,10 @@ public:
     bool flush() override;
 
     void set_ampdu_strict(bool on);
+    // the reference's ifdebug after construction, and where its lines go (stdout by default)
+    void set_debug(bool on) { d_debug = on; }
+    void set_debug_output(FILE *f) { d_debugOut = f; }
+    uint64_t packets_correct() const { return d_nPktCorrect; }
     // soft bits a round holds at most before it is cut (at the next packet boundary) whatever the packet count
     void set_max_hold(size_t items) { d_maxHold = items < 4096 ? 4096 : items; }
     uint64_t packets_seen() const { return d_nSeen; }
@@ -318,12 +323,14 @@ private:
     // One stretch of the stream on its way through the GPU: its soft bits as they came (packets back to back, whatever
     // lies between them included), a descriptor per packet.  While one round is filled, the ones before it decode on
     // the streams of their own contexts and are published in order.
+    struct debug_tags { float cfo, snr, rssi, sssnr0, sssnr1; };
     struct round {
         std::unique_ptr<gpu_session> gpu;
         float *llr = nullptr;              // device arena
         size_t cap = 0, n = 0;             // soft bits it can hold / holds
         uint64_t base = 0;                 // absolute index of item 0
         std::vector<gr80211_dec_desc> desc;
+        std::vector<debug_tags> dbg;       // with ifdebug: the tags the debug lines quote, one per packet
         std::vector<std::pair<size_t, pdu_t>> ready;  // channel messages of sounding packets and how many packets of
                                                       // the round precede each
         enum { FREE, FILL, DECODE } state = FREE;
@@ -333,8 +340,11 @@ private:
     bool cut();                                    // the round being filled goes to the decoder; another one is filled
     bool advance(bool wait_front, bool wait_all);
     void publish_ready(round &r, size_t upto_desc, size_t &at);
+    void debug_lines(const gr80211_dec_desc &d, const debug_tags &t, uint64_t n_pub);
 
     bool d_debug;
+    FILE *d_debugOut = nullptr;  // where the debug lines go (stdout unless set_debug_output was called)
+    uint64_t d_nPktCorrect = 0, d_legacyMcsCount[8] = {}, d_htMcsCount[8] = {}, d_vhtMcsCount[10] = {};
     int d_batch;
     uploader d_up;
     static constexpr int N_ROUNDS = 3;

@@ -129,6 +129,11 @@ int gr80211_block_set_option(gr80211_block *b, int option, int value)
         if (dm) dm->set_mu_pos(value);
         return 0;
     }
+    if (option == GR80211_OPT_DEBUG) {
+        if (!d) return -1;
+        d->set_debug(value != 0);
+        return 0;
+    }
     if (option == GR80211_OPT_AMPDU_STRICT) {
         if (d) d->set_ampdu_strict(value != 0);
         if (r) r->set_ampdu_strict(value != 0);

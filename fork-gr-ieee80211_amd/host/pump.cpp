@@ -399,7 +399,7 @@ static int run(int argc, char **argv)
         if (n_rx == 2) n = std::min(n, iq1.size() / 8);
         signal::sptr sg = signal::make(n_rx, batch, 0);
         demod::sptr dm = demod::make(n_rx, 0, 2, batch, 0);
-        decode::sptr dc = decode::make(false, batch, 0);
+        decode::sptr dc = decode::make(getenv("GR80211_PUMP_DEBUG") != nullptr, batch, 0);
         dc->set_msg_handler(on_msg);
         link l_sync(1), l_a(8), l_b(8), l_s0(8), l_s1(8), l_llr(4);
         l_sync.buf.assign(n, 0);
@@ -461,7 +461,7 @@ static int run(int argc, char **argv)
         if (n_rx == 2) n = std::min(n, iq1.size() / 8);
         signal::sptr sg = signal::make(n_rx, batch, 0);
         demod::sptr dm = demod::make(n_rx, 0, 2, batch, 0);
-        decode::sptr dc = decode::make(false, batch, 0);
+        decode::sptr dc = decode::make(getenv("GR80211_PUMP_DEBUG") != nullptr, batch, 0);
         dc->set_msg_handler(on_msg);
         const char *pin = getenv("GR80211_PUMP_PIN");
         const bool pinned = !pin || pin[0] != '0';
@@ -540,7 +540,7 @@ static int run(int argc, char **argv)
     }
     if (argc >= 6 && !strcmp(argv[1], "decode")) {
         const int chunk = atoi(argv[2]), batch = atoi(argv[3]);
-        decode::sptr b = decode::make(false, batch, 0);
+        decode::sptr b = decode::make(getenv("GR80211_PUMP_DEBUG") != nullptr, batch, 0);
         if (!b->last_error().empty()) {
             fprintf(stderr, "block error: %s\n", b->last_error().c_str());
             return 1;

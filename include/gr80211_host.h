@@ -72,6 +72,9 @@ typedef struct {
 
 #define GR80211_OPT_MU_POS 0       /* ieee80211::demod::make(mupos, mugid): position in VHT MU groups, 0 or 1 */
 #define GR80211_OPT_AMPDU_STRICT 1 /* 1: the standard's A-MPDU de-aggregation instead of the reference's */
+#define GR80211_OPT_DEBUG 2        /* ieee80211::decode::make(ifdebug) (DECODE only): 1 = one line per packet on stdout with the
+                                      running per-MCS counts of packets whose FCS held, in the reference's wording
+                                      (lib/decode_impl.cc:375-411,453-509: "ieee80211 decode, vht crc32 correct, total:...") */
 
 typedef struct gr80211_block gr80211_block;
 typedef void (*gr80211_msg_fn)(void *user, const uint8_t *blob, int len);

@@ -582,6 +582,38 @@ def test_pump_chain_of_three_blocks(tmp_path, oracle, chunk, batch):
     assert "frames=%d " % n_frames in stat + " ", stat
 
 
+def test_decode_block_debug_counters_in_the_references_wording(tmp_path, oracle):
+    """decode made with ifdebug prints, per packet, the running per-MCS counts of packets whose FCS held, worded as the
+    reference's lines are (lib/decode_impl.cc:375-411,453-509), so that its performance scripts can scrape them
+    (tools/performance/perf_siso.py:105-118: last line with "crc32" and the format's name, fields 3 ... 3 + nMcs).  The
+    last line of every format must count exactly the messages of that format and MCS that were published."""
+    iq0, triggers, frames = siso_stream(0.002, 6)
+    tf, files = write_stream(tmp_path, iq0, None, triggers)
+    p = subprocess.run([PUMP, "chain", "1", "4096", "1000", str(tf)] + [str(f) for f in files], capture_output=True, text=True,
+                       timeout=170, env=dict(os.environ, GR80211_PUMP_DEBUG="1"))
+    assert p.returncode == 0, p.stderr[-2000:]
+    pdus = [bytes.fromhex(l.split()[1]) for l in p.stdout.splitlines() if l.startswith("PDU ")]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("ieee80211 decode, ")]
+    assert lines and all("crc32" in l for l in lines)
+    total = 0
+    for fmt, name, n_mcs in ((0, "legacy", 8), (1, "ht", 8), (2, "vht", 10)):
+        want = [0] * n_mcs
+        for m in pdus:
+            if m[0] == fmt:
+                want[m[-1] % 8 if fmt == 1 else m[-1]] += 1
+        mine = [l for l in lines if ", %s crc32" % name in l]
+        if not any(want):
+            continue
+        items = mine[-1].split(",")          # as the reference's scraper reads it
+        got = [int(items[i].split(":")[1]) for i in range(3, 3 + n_mcs)]
+        assert got == want, (name, got, want)
+        assert items[2 + n_mcs + 1].startswith("cfo:") and items[2 + n_mcs + 3].startswith("rssi:")
+        total += sum(want)
+    assert total == len([m for m in pdus if m[0] in (0, 1, 2)]) > 0
+    # the shared total in the very last line counts every packet of every format
+    assert int(lines[-1].split("total:")[1].split(",")[0]) == total
+
+
 @pytest.mark.parametrize("n_rx,chunk,batch", [(1, 4096, 1000), (1, 777, 2), (2, 1500, 3)])
 def test_streaming_abi_from_plain_c(tmp_path, oracle, n_rx, chunk, batch):
     """signal -> demod -> decode through gr80211_block_work_out / gr80211_block_work from a C program (tags as
