@@ -583,7 +583,8 @@ def main():
                          "thread each; N = 1 only; 1 = skip)")
     ap.add_argument("--pool", type=int, default=-1,
                     help="work sets (soft bits, survivor words, decoded bits) the rotating contexts share "
-                         "(gr80211_use_work_pool); 0 = every context its own; -1 = three when more than three contexts rotate "
+                         "(gr80211_use_work_pool: that many survivor buffers and two soft-bit buffers more); 0 = every context its "
+                         "own; -1 = two when more than three contexts rotate "
                          "and their own buffers would take more than 48 GB together")
     ap.add_argument("--latency", type=int, default=1, help="also time small batches one at a time (0 = skip)")
     ap.add_argument("--force-collective", action="store_true",
@@ -681,7 +682,7 @@ def main():
         probe.close()
         del probe
         torch.cuda.empty_cache()
-        pool = 3 if own_bytes * pipe > 48e9 else 0
+        pool = 2 if own_bytes * pipe > 48e9 else 0
     rot = Rotation(torch, dist, pkg, shard, local, dev, parts, n, out_stride, pipe, collective, compact, ctx,
                    side_copy=args.side_copy and not collective, pool=pool)
     out, out_len, n_pdu = rot.outs[0]

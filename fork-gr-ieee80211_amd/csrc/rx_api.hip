@@ -38,7 +38,9 @@ void *g_scratch[64] = {};
 }  // namespace
 
 struct PoolLeaseBase {
-    virtual void engage() = 0;  // from here on the call's kernels touch the set: wait (on the device) for its last user
+    // from here on the call's kernels touch the pooled buffer of that kind (0 soft bits, 1 survivor words and decoded
+    // bits): wait, on the device, for its last user
+    virtual void engage(int kind) = 0;
     virtual ~PoolLeaseBase() = default;
 };
 
@@ -169,50 +171,58 @@ void release(Buf &b)
 
 hipStream_t pick(gr80211_ctx *c, void *stream) { return stream ? (hipStream_t)stream : c->stream; }
 
-// ---- work sets shared by the contexts of a device ---------------------------------------------------------------
-// The three large work buffers of a batch (soft bits, survivor words, decoded bits) are live from the demodulator to
-// the end of the decoder only.  Contexts that rotate over batches (one stream each, so that kernels of neighbouring
-// batches overlap) therefore need fewer sets than there are contexts: a context that has joined the pool takes a set
-// for the length of one batch call and hands it back with an event recorded behind the batch's last kernel; the next
-// taker's stream waits for that event (on the device: the host never blocks).
-struct WorkSet {
-    Buf llr, dec, bitsw;
-    hipEvent_t ev = nullptr;   // end of the last batch that used the set
+// ---- work buffers shared by the contexts of a device -------------------------------------------------------------
+// The three large work buffers of a batch are live for part of it only: the soft bits from the demodulator to the end
+// of the decoder, the survivor words and decoded bits for the length of the decoder.  Contexts that rotate over batches
+// (one stream each, so that kernels of neighbouring batches overlap) therefore need fewer of them than there are
+// contexts, and fewer survivor buffers than soft-bit buffers: decoders overlap two at a time (the next one fills the
+// wave slots the running one leaves free), while the demodulator of the batch after next should not have to wait for
+// the oldest decoder to end.  A context that has joined the pool takes a soft-bit buffer and a survivor buffer for the
+// length of one batch call and hands them back with an event recorded behind the batch's last kernel; the next taker's
+// stream waits for that event on the device (the host never blocks), and only from the first kernel on that touches
+// the buffer: the demodulator for the soft bits, the decoder for the survivor words.
+enum { POOL_SOFT = 0, POOL_SURV = 1, POOL_KINDS = 2 };
+struct PoolItem {
+    Buf a, b;                  // POOL_SOFT: soft bits, -; POOL_SURV: survivor words, decoded bits
+    hipEvent_t ev = nullptr;   // end of the last batch that used it
     bool pending = false;      // ev has been recorded and may not have completed
     bool busy = false;         // held by a batch call that is still queuing its kernels (another host thread)
-    uint64_t released = 0;     // order of hand-backs: the set handed back longest ago is taken first
+    uint64_t released = 0;     // order of hand-backs: the one handed back longest ago is taken first
 };
 struct DevicePool {
-    std::vector<WorkSet *> sets;
+    std::vector<PoolItem *> items[POOL_KINDS];
     int users = 0;             // contexts of this device that have joined
-    int max_sets = 0;
+    int max_items[POOL_KINDS] = {0, 0};
+    size_t cap[POOL_KINDS][2] = {{0, 0}, {0, 0}};  // the largest buffers of each kind so far (bytes)
     uint64_t clock = 0;
 };
 std::mutex g_pool_mutex;
 DevicePool g_pool[64];
 
-// A batch call's hold on a work set: the set's buffers stand in for the context's own for the length of the call.
+// A batch call's hold on pooled buffers: they stand in for the context's own for the length of the call.
 struct PoolLease : PoolLeaseBase {
     gr80211_ctx *c;
-    WorkSet *ws = nullptr;
+    PoolItem *it[POOL_KINDS] = {nullptr, nullptr};
     hipStream_t s;
-    bool must_wait = false;  // the set's last batch may still be running
+    bool must_wait[POOL_KINDS] = {false, false};  // the buffer's last batch may still be running
     Buf own_llr, own_dec, own_bitsw;
     PoolLease(gr80211_ctx *cc, hipStream_t stream);
     ~PoolLease() override;
-    void engage() override;
+    void engage(int kind) override;
     PoolLease(const PoolLease &) = delete;
     PoolLease &operator=(const PoolLease &) = delete;
+
+private:
+    PoolItem *take(DevicePool &dp, int kind, bool &wait);
+    static void level(Buf &b, size_t bytes);
 };
 
-
-PoolLease::PoolLease(gr80211_ctx *cc, hipStream_t stream) : c(cc), s(stream)
+// Under g_pool_mutex.  nullptr: every buffer of the kind is held by a call in progress on another thread (or no event
+// could be made): the context's own buffer serves.
+PoolItem *PoolLease::take(DevicePool &dp, int kind, bool &wait)
 {
-    if (c->pool_sets <= 0) return;
-    std::lock_guard<std::mutex> lk(g_pool_mutex);
-    DevicePool &dp = g_pool[c->device];
-    WorkSet *done = nullptr, *oldest = nullptr;
-    for (WorkSet *w : dp.sets) {
+    PoolItem *done = nullptr, *oldest = nullptr;
+    for (PoolItem *w : dp.items[kind]) {
         if (w->busy) continue;
         if (w->pending && hipEventQuery(w->ev) == hipSuccess) w->pending = false;
         if (!w->pending) {
@@ -222,54 +232,88 @@ PoolLease::PoolLease(gr80211_ctx *cc, hipStream_t stream) : c(cc), s(stream)
         }
     }
     (void)hipGetLastError();  // hipErrorNotReady from the queries above is not an error
-    if (done) {
-        ws = done;
-    } else if ((int)dp.sets.size() < dp.max_sets) {
-        WorkSet *w = new WorkSet();
+    wait = false;
+    if (done) return done;
+    if ((int)dp.items[kind].size() < dp.max_items[kind]) {
+        PoolItem *w = new PoolItem();
         if (hipEventCreateWithFlags(&w->ev, hipEventDisableTiming) != hipSuccess) {
             delete w;
-            return;  // the context's own buffers serve
+            return nullptr;
         }
-        dp.sets.push_back(w);
-        ws = w;
-    } else if (oldest) {
-        // its last batch is still running: this batch's kernels that touch the set queue up behind it on the device
-        // (engage), the ones before them -- preamble, scheduler -- do not
-        must_wait = true;
-        ws = oldest;
-    } else {
-        return;  // every set is held by a call in progress on another thread: the context's own buffers serve
+        dp.items[kind].push_back(w);
+        return w;
     }
-    ws->busy = true;
-    own_llr = c->llr, own_dec = c->dec, own_bitsw = c->bitsw;
-    c->llr = ws->llr, c->dec = ws->dec, c->bitsw = ws->bitsw;
-    c->lease = this;
+    // its last batch is still running: this batch's kernels that touch the buffer queue up behind it on the device
+    // (engage), the ones before them do not
+    wait = oldest != nullptr;
+    return oldest;
 }
 
-void PoolLease::engage()
+PoolLease::PoolLease(gr80211_ctx *cc, hipStream_t stream) : c(cc), s(stream)
 {
-    if (!ws || !must_wait) return;
-    must_wait = false;
-    if (hipStreamWaitEvent(s, ws->ev, 0) != hipSuccess) (void)hipEventSynchronize(ws->ev);
+    if (c->pool_sets <= 0) return;
+    std::lock_guard<std::mutex> lk(g_pool_mutex);
+    DevicePool &dp = g_pool[c->device];
+    own_llr = c->llr, own_dec = c->dec, own_bitsw = c->bitsw;
+    for (int k = 0; k < POOL_KINDS; k++) {
+        it[k] = take(dp, k, must_wait[k]);
+        if (!it[k]) continue;
+        it[k]->busy = true;
+        // Every buffer of a kind is as large as the largest of them: a batch queued without the wait must find the
+        // room the batches before it found, whichever buffer it happens to get.  (Freeing memory waits for the
+        // device, so a buffer still in use by an earlier batch is safe to replace; sizes settle within the first
+        // batches.)
+        level(it[k]->a, dp.cap[k][0]);
+        level(it[k]->b, dp.cap[k][1]);
+    }
+    if (it[POOL_SOFT]) c->llr = it[POOL_SOFT]->a;
+    if (it[POOL_SURV]) c->dec = it[POOL_SURV]->a, c->bitsw = it[POOL_SURV]->b;
+    if (it[POOL_SOFT] || it[POOL_SURV]) c->lease = this;
+}
+
+void PoolLease::engage(int kind)
+{
+    if (!it[kind] || !must_wait[kind]) return;
+    must_wait[kind] = false;
+    if (hipStreamWaitEvent(s, it[kind]->ev, 0) != hipSuccess) (void)hipEventSynchronize(it[kind]->ev);
 }
 
 PoolLease::~PoolLease()
 {
-    if (!ws) return;
+    if (!it[POOL_SOFT] && !it[POOL_SURV]) return;
     c->lease = nullptr;
-    // the call may have grown the buffers: the set keeps what the context holds now
-    ws->llr = c->llr, ws->dec = c->dec, ws->bitsw = c->bitsw;
-    c->llr = own_llr, c->dec = own_dec, c->bitsw = own_bitsw;
-    const bool recorded = hipEventRecord(ws->ev, s) == hipSuccess;
+    // the call may have grown the buffers: the pool keeps what the context holds now
+    if (it[POOL_SOFT]) it[POOL_SOFT]->a = c->llr, c->llr = own_llr;
+    if (it[POOL_SURV]) it[POOL_SURV]->a = c->dec, it[POOL_SURV]->b = c->bitsw, c->dec = own_dec, c->bitsw = own_bitsw;
+    bool recorded[POOL_KINDS] = {false, false};
+    bool all = true;
+    for (int k = 0; k < POOL_KINDS; k++)
+        if (it[k]) all = (recorded[k] = hipEventRecord(it[k]->ev, s) == hipSuccess) && all;
+    if (!all) (void)hipStreamSynchronize(s);  // without the event a buffer is only safe once the stream has run dry
     std::lock_guard<std::mutex> lk(g_pool_mutex);
     DevicePool &dp = g_pool[c->device];
-    ws->pending = recorded;
-    if (!recorded) (void)hipStreamSynchronize(s);  // without the event the set is only safe once the stream has run dry
-    ws->busy = false;
-    ws->released = ++dp.clock;
+    for (int k = 0; k < POOL_KINDS; k++) {
+        if (!it[k]) continue;
+        it[k]->pending = recorded[k];
+        it[k]->busy = false;
+        it[k]->released = ++dp.clock;
+        dp.cap[k][0] = std::max(dp.cap[k][0], it[k]->a.cap);
+        dp.cap[k][1] = std::max(dp.cap[k][1], it[k]->b.cap);
+    }
 }
 
-// A context leaves the pool (or is destroyed): with the last user gone the sets are freed.
+// Makes b at least `bytes` large, without headroom of its own (the size comes from a sibling that has it already).
+void PoolLease::level(Buf &b, size_t bytes)
+{
+    if (b.cap >= bytes) return;
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr;
+    b.cap = 0;
+    if (hipMalloc(&b.p, bytes) == hipSuccess) b.cap = bytes;
+    else b.p = nullptr, (void)hipGetLastError();  // the batch's own ensure() reports the shortage
+}
+
+// A context leaves the pool (or is destroyed): with the last user gone the buffers are freed.
 void pool_leave(gr80211_ctx *c)
 {
     if (c->pool_sets <= 0) return;
@@ -278,15 +322,17 @@ void pool_leave(gr80211_ctx *c)
     DevicePool &dp = g_pool[c->device];
     if (--dp.users > 0) return;
     (void)hipDeviceSynchronize();
-    for (WorkSet *w : dp.sets) {
-        release(w->llr);
-        release(w->dec);
-        release(w->bitsw);
-        if (w->ev) (void)hipEventDestroy(w->ev);
-        delete w;
+    for (int k = 0; k < POOL_KINDS; k++) {
+        for (PoolItem *w : dp.items[k]) {
+            release(w->a);
+            release(w->b);
+            if (w->ev) (void)hipEventDestroy(w->ev);
+            delete w;
+        }
+        dp.items[k].clear();
+        dp.max_items[k] = 0;
+        dp.cap[k][0] = dp.cap[k][1] = 0;
     }
-    dp.sets.clear();
-    dp.max_sets = 0;
     dp.users = 0;
 }
 
@@ -425,7 +471,7 @@ int finish_decode_stages(gr80211_ctx *c, hipStream_t s, int n, bool from_iq, con
     // a batch launched without waiting for the scheduler hands its kernels the scheduler's record on the device
     const SchedTotals *dt = known ? (const SchedTotals *)c->totals_d.p : nullptr;
     const float *llr = d_llr_in;
-    if (c->lease) c->lease->engage();  // the kernels from here on use the (possibly shared) work buffers
+    if (c->lease) c->lease->engage(0);  // the demodulator writes the (possibly shared) soft-bit buffer
     if (from_iq) {
         if ((rc = ensure(c, c->llr, (size_t)(tot.llr_floats + 64) * sizeof(float)))) return rc;
         launch_demod(d_iq0, d_iq1, arena_len, d_desc, n, info, c->chan1.p, c->chan2.p, (float *)c->llr.p, dt, s,
@@ -441,6 +487,7 @@ int finish_decode_stages(gr80211_ctx *c, hipStream_t s, int n, bool from_iq, con
         if (tot.n_groups > 0) {
             if ((rc = ensure(c, c->dec, (size_t)(tot.dec_words + 128) * sizeof(uint32_t)))) return rc;
             if ((rc = ensure(c, c->bitsw, (size_t)(tot.bits_words + 64) * sizeof(uint32_t)))) return rc;
+            if (c->lease) c->lease->engage(1);  // the decoder writes the (possibly shared) survivor words
             // a batch of few groups leaves SIMDs idle for a whole trellis: share each group among four waves
             int gw = c->group_waves;
             // four waves per group while their quarter-waves fit two to a SIMD, two up to one group per SIMD, one beyond
@@ -1708,7 +1755,12 @@ int gr80211_use_work_pool(gr80211_ctx *c, int max_sets)
     DevicePool &dp = g_pool[c->device];
     if (c->pool_sets <= 0) dp.users++;
     c->pool_sets = max_sets;
-    if (max_sets > dp.max_sets) dp.max_sets = max_sets;
+    // max_sets survivor buffers and two soft-bit buffers more, so that the demodulators of the batches after next need not
+    // wait for the oldest decoder (GR80211_POOL_SOFT_EXTRA=<n>: another number, for experiments)
+    int extra = 2;
+    if (const char *e = getenv("GR80211_POOL_SOFT_EXTRA")) extra = atoi(e);
+    if (max_sets > dp.max_items[POOL_SURV]) dp.max_items[POOL_SURV] = max_sets;
+    if (max_sets + extra > dp.max_items[POOL_SOFT]) dp.max_items[POOL_SOFT] = max_sets + extra > 1 ? max_sets + extra : 1;
     return GR80211_OK;
 }
 
@@ -1719,9 +1771,10 @@ int gr80211_work_memory(gr80211_ctx *c, uint64_t *own_bytes, uint64_t *pool_byte
     std::lock_guard<std::mutex> lk(g_pool_mutex);
     const DevicePool &dp = g_pool[c->device];
     uint64_t b = 0;
-    for (const WorkSet *w : dp.sets) b += (uint64_t)w->llr.cap + w->dec.cap + w->bitsw.cap;
+    for (int k = 0; k < POOL_KINDS; k++)
+        for (const PoolItem *w : dp.items[k]) b += (uint64_t)w->a.cap + w->b.cap;
     if (pool_bytes) *pool_bytes = b;
-    if (pool_sets) *pool_sets = (int)dp.sets.size();
+    if (pool_sets) *pool_sets = (int)dp.items[POOL_SURV].size();
     return GR80211_OK;
 }
 

@@ -253,20 +253,21 @@ int gr80211_rx_capture(gr80211_ctx *ctx, const void *d_iq0, const void *d_iq1, u
                        gr80211_frame_desc *d_desc_out, int *n_frames, void *stream);
 
 /*
- * Work memory shared by the contexts of a GPU.  A batch's three large work buffers (soft bits, survivor words,
- * decoded bits: 6.5 + 9.7 + 0.15 GB for 100 000 frames of 1500 bytes at VHT MCS8) are in use from its demodulator to
- * the end of its decoder only, so contexts that take turns (one stream each, batches of neighbouring steps
- * overlapping) need fewer sets of them than there are contexts.  After this call the context takes a set from its
- * GPU's pool for the length of every batch call that decodes (gr80211_rx_batch, _rx_finish, _rx_capture, _rx_resume,
- * _decode_batch) instead of keeping its own; the pool creates at most max_sets sets (the largest value any context
- * of the GPU asked for), grows a set like a context grows its buffers, and when every set is still in use by an
- * earlier batch the new batch's kernels wait, on the device, for the set that was handed back first -- the host never
- * blocks.  GR80211_FLAG_NO_WAIT batches are sized by the set they happen to get: warm the pool with as many batches
- * without the flag as it has sets.  max_sets = 0 leaves the pool (the last context to leave frees the sets).  The
- * environment variable GR80211_WORK_POOL=<n> makes every new context join with max_sets = n.  Entry points that hand
- * out pointers into the work buffers (gr80211_demod_batch, gr80211_demod_tagged_batch) and
- * gr80211_decode_batch_noalloc keep to the context's own memory.  No counterpart in the reference, whose blocks hold
- * fixed arrays (lib/decode_impl.h:73).
+ * Work memory shared by the contexts of a GPU.  A batch's large work buffers (soft bits; survivor words and decoded
+ * bits: 6.5 + 9.7 + 0.15 GB for 100 000 frames of 1500 bytes at VHT MCS8) are in use for part of it only -- the soft
+ * bits from its demodulator to the end of its decoder, the others for the length of its decoder -- so contexts that
+ * take turns (one stream each, batches of neighbouring steps overlapping) need fewer of them than there are contexts.
+ * After this call the context takes a soft-bit buffer and a survivor buffer from its GPU's pool for the length of every
+ * batch call that decodes (gr80211_rx_batch, _rx_finish, _rx_capture, _rx_resume, _decode_batch) instead of keeping
+ * its own; the pool creates at most max_sets survivor buffers and max_sets + 2 soft-bit buffers (max_sets: the largest
+ * value any context of the GPU asked for), grows them like a context grows its buffers, and when every buffer of a
+ * kind is still in use by an earlier batch the new batch's kernels that touch it wait, on the device, for the one that
+ * was handed back first -- the host never blocks.  GR80211_FLAG_NO_WAIT batches are sized by the buffers they happen
+ * to get: warm the pool with max_sets + 2 batches without the flag.  max_sets = 0 leaves the pool (the last context to
+ * leave frees the buffers).  The environment variable GR80211_WORK_POOL=<n> makes every new context join with
+ * max_sets = n.  Entry points that hand out pointers into the work buffers (gr80211_demod_batch,
+ * gr80211_demod_tagged_batch) and gr80211_decode_batch_noalloc keep to the context's own memory.  No counterpart in
+ * the reference, whose blocks hold fixed arrays (lib/decode_impl.h:73).
  */
 int gr80211_use_work_pool(gr80211_ctx *ctx, int max_sets);
 /* Bytes of the three large work buffers the context holds itself, bytes and number of sets of its GPU's pool (each nullable). */

@@ -899,8 +899,9 @@ def test_copies_by_kernel_over_the_link(pkg, rxctx):
 
 def test_six_contexts_on_a_pool_of_three_work_sets(pkg):
     """Six contexts take turns over batches of different sizes (as the benchmark's rotation does) while sharing
-    three sets of work buffers: every batch gives what a context with buffers of its own gives, with and without the
-    wait inside the call, the pool never holds more than three sets, and leaving it frees them."""
+    pooled work buffers (three for survivor words, five for soft bits): every batch gives what a context with buffers
+    of its own gives, with and without the wait inside the call, the pool never holds more than it may, and leaving it
+    frees everything."""
     import torch
     tx = pkg.txgen
     rng = np.random.default_rng(61)
@@ -942,7 +943,7 @@ def test_six_contexts_on_a_pool_of_three_work_sets(pkg):
         assert sets <= 3 and pool > 0
         assert all(c.work_memory()[0] == 0 for c in ctxs)   # nobody grew buffers of its own
         one = ref.work_memory()[0]
-        assert pool <= 3 * one * 1.05 + (1 << 20)
+        assert pool <= 5 * one * 1.05 + (1 << 20)   # three survivor buffers, five soft-bit buffers
         for c in ctxs:
             c.use_work_pool(0)
         assert ctxs[0].work_memory()[1:] == (0, 0)
