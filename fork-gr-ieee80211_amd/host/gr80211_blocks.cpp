@@ -7,6 +7,9 @@
 #include <cstdlib>
 #include <cstring>
 
+#if defined(__SSE2__)
+#include <emmintrin.h>
+#endif
 #include <arpa/inet.h>
 #include <netdb.h>
 #include <sys/socket.h>
@@ -424,6 +427,16 @@ bool device_fifo::release_front(size_t items)
     return true;
 }
 
+// GR80211_COPY_PAST_CACHE=0 switches the streaming stores of copy_past_cache off (A/B measurements).
+static bool getenv_flag_copy_past_cache()
+{
+    static const bool on = [] {
+        const char *e = getenv("GR80211_COPY_PAST_CACHE");
+        return !e || e[0] != '0';
+    }();
+    return on;
+}
+
 void out_stream::push(const void *src, size_t items)
 {
     if (items == 0) return;
@@ -470,6 +483,40 @@ void out_stream::release_refs(const void *lo, const void *hi)
     }
 }
 
+// A copy for runs that nobody on this core reads again soon (items on their way from page-locked staging memory, which
+// the GPU wrote, to a scheduler buffer, which another thread or the GPU reads): stores that go past the cache, so that
+// the destination's lines are not fetched before they are overwritten and the copy does not push the thread's working
+// set out.  Short runs and x86 machines without SSE2 take memcpy.
+static void copy_past_cache(void *dst, const void *src, size_t n)
+{
+#if defined(__SSE2__)
+    if (n >= 4096 && getenv_flag_copy_past_cache()) {
+        uint8_t *d = static_cast<uint8_t *>(dst);
+        const uint8_t *s = static_cast<const uint8_t *>(src);
+        const size_t head = (16 - (reinterpret_cast<uintptr_t>(d) & 15)) & 15;
+        if (head) {
+            memcpy(d, s, head);
+            d += head, s += head, n -= head;
+        }
+        size_t k = 0;
+        for (; k + 64 <= n; k += 64) {
+            const __m128i a = _mm_loadu_si128(reinterpret_cast<const __m128i *>(s + k));
+            const __m128i b = _mm_loadu_si128(reinterpret_cast<const __m128i *>(s + k + 16));
+            const __m128i c = _mm_loadu_si128(reinterpret_cast<const __m128i *>(s + k + 32));
+            const __m128i e = _mm_loadu_si128(reinterpret_cast<const __m128i *>(s + k + 48));
+            _mm_stream_si128(reinterpret_cast<__m128i *>(d + k), a);
+            _mm_stream_si128(reinterpret_cast<__m128i *>(d + k + 16), b);
+            _mm_stream_si128(reinterpret_cast<__m128i *>(d + k + 32), c);
+            _mm_stream_si128(reinterpret_cast<__m128i *>(d + k + 48), e);
+        }
+        _mm_sfence();
+        if (k < n) memcpy(d + k, s + k, n - k);
+        return;
+    }
+#endif
+    memcpy(dst, src, n);
+}
+
 int out_stream::pop(void *dst, int max_items, uint64_t written, std::vector<tag_t> &out)
 {
     const size_t n = std::min<size_t>(pending(), max_items > 0 ? (size_t)max_items : 0);
@@ -479,7 +526,8 @@ int out_stream::pop(void *dst, int max_items, uint64_t written, std::vector<tag_
     while (want > 0) {
         seg &g = d_segs.front();
         const size_t take = std::min(want, g.bytes - g.head);
-        memcpy(d, (g.ext ? g.ext : g.own.data()) + g.head, take);
+        if (g.ext) copy_past_cache(d, g.ext + g.head, take);
+        else memcpy(d, g.own.data() + g.head, take);
         g.head += take;
         d += take;
         want -= take;
@@ -1481,8 +1529,9 @@ demod::sptr demod::make(int n_rx, int mupos, int, int batch_frames, int device)
 
 demod::demod(int n_rx, int mupos, int batch_frames, int device)
     : block(n_rx == 2 ? 2 : 1, 1), d_nrx(n_rx == 2 ? 2 : 1), d_muPos(mupos ? 1 : 0), d_batch(batch_frames < 1 ? 1 : batch_frames),
-      d_device(device), d_out(sizeof(float))
+      d_device(device), d_out(sizeof(float)), d_up(new uploader(device))
 {
+    if (!d_up->ok()) d_err = "gr80211_create failed";
     for (int i = 0; i < N_ROUNDS; i++) {
         d_round.emplace_back(new round());
         d_round.back()->gpu.reset(new gpu_session(device));
@@ -1495,6 +1544,9 @@ demod::~demod()
     if (getenv("GR80211_BLOCK_PROFILE"))
         fprintf(stderr, "demod block: %llu frames, %llu rounds; host seconds: harvest %.4f tags %.4f copy in %.4f soft bits out %.4f other %.4f\n",
                 (unsigned long long)d_nSeen, (unsigned long long)d_nRounds, d_tHarvest, d_tTags, d_tCopyIn, d_tPop, d_tOther);
+    // nothing of this block may still be on its way when its buffers go
+    d_up->log().drain();
+    if (d_up->ok()) d_up->sync();
     for (auto &r : d_round) {
         if (r->worker.joinable()) r->worker.join();
         for (int a = 0; a < 2; a++)
@@ -1558,15 +1610,32 @@ int demod::general_work(int noutput_items, gr_vector_int &ninput_items, gr_vecto
         consume_each(0);
         return 0;
     }
+    if (d_mode == M_UNKNOWN && n > 0) {
+        // windows in page-locked memory go to the GPU as they are; others are collected frame by frame first
+        bool pinned = d_up->ok();
+        for (int a = 0; a < d_nrx; a++) pinned = pinned && is_pinned(input_items[(size_t)a], (size_t)n * sizeof(gr_complex));
+        if (const char *e = getenv("GR80211_DEMOD_DIRECT")) pinned = pinned && e[0] != '0';  // experiments
+        d_mode = pinned ? M_DIRECT : M_STAGED;
+    }
     if (d_out.pending() > OUT_QUEUE_LIMIT) n = 0;  // input is only taken while the soft bits produced find room
     int used = 0;
     std::vector<tag_t> tags;
+    if (d_mode == M_DIRECT) {
+        used = fill_direct(n, input_items);
+        lap(d_tCopyIn);
+        if (used < 0) {
+            consume_each(0);
+            return 0;
+        }
+        n = 0;  // the loop below is the other mode's
+    }
     while (used < n) {
         if (!d_fill) {
             d_fill = free_round();
             if (!d_fill) break;  // every round is on its way: the input waits
             d_fill->state.store(R_FILL);
             d_fill->n = 0;
+            d_fill->direct = false;
             d_fill->desc.clear();
             d_fill->chan.clear();
         }
@@ -1637,7 +1706,8 @@ int demod::general_work(int noutput_items, gr_vector_int &ninput_items, gr_vecto
             }
         }
     }
-    consume_each(used);
+    if (d_mode != M_DIRECT) consume_each(used);
+    n = ninput_items[0];
     if (output_items.empty()) return 0;
     tags.clear();
     lap(d_tOther);
@@ -1659,6 +1729,129 @@ int demod::general_work(int noutput_items, gr_vector_int &ninput_items, gr_vecto
     return produced;
 }
 
+// Page-locked input windows: the frames' items travel to the round's device arena straight from the window, one
+// asynchronous piece per call (the arena mirrors the stream from the round's first frame on, padding and all), and the
+// call consumes the items whose pieces have arrived.  The state machine runs ahead of what has been consumed: it
+// resumes where the last call's pieces ended.  Returns the items consumed, -1 on an error.
+int demod::fill_direct(int n, gr_vector_const_void_star &input_items)
+{
+    const uint64_t r0 = nitems_read(0);
+    upload_log &log = d_up->log();
+    if (log.enqueued() < r0) log.set_enqueued(r0);
+    int used = (int)std::min<uint64_t>(log.enqueued() - r0, (uint64_t)n);
+    int span = used;  // window items [span, used) have been looked at and not sent yet
+    // window items [span, upto) go where they belong: to the arena of the round being filled, or nowhere
+    auto send_span = [&](int upto) -> bool {
+        if (upto <= span) return true;
+        round *r = d_fill;
+        if (!r || !r->direct) {
+            log.add(nullptr, 0, r0 + (uint64_t)upto);  // no frame wants them: free at once
+            span = upto;
+            return true;
+        }
+        const size_t cnt = (size_t)(upto - span);
+        const uint64_t at = r0 + (uint64_t)span - r->base;
+        bool pinned = true;
+        const char *src[2];
+        char *dst[2];
+        for (int a = 0; a < d_nrx; a++) {
+            src[a] = reinterpret_cast<const char *>(static_cast<const gr_complex *>(input_items[(size_t)a]) + span);
+            dst[a] = r->dev[a] + at * sizeof(gr_complex);
+            pinned = pinned && is_pinned(src[a], cnt * sizeof(gr_complex));
+        }
+        if (!d_up->send(*r->gpu, d_nrx, src, dst, cnt, sizeof(gr_complex), r0 + (uint64_t)span, pinned, d_err)) return false;
+        r->n = (size_t)(at + cnt);
+        span = upto;
+        return true;
+    };
+    std::vector<tag_t> tags;
+    while (used < n) {
+        if (!d_fill) {
+            if (!send_span(used)) return -1;
+            d_fill = free_round();
+            if (!d_fill) break;  // every round is on its way: the input waits
+            d_fill->state.store(R_FILL);
+            d_fill->n = 0;
+            d_fill->direct = false;  // until its first frame
+            d_fill->desc.clear();
+            d_fill->chan.clear();
+        }
+        round &r = *d_fill;
+        if (d_state == S_IDLE) {
+            const uint64_t at = r0 + (uint64_t)used;
+            get_tags_in_range(tags, 0, at, at + 1);
+            if (tags.empty()) {
+                get_tags_in_range(tags, 0, at + 1, r0 + (uint64_t)n);
+                used = tags.empty() ? n : (int)(tags[0].offset - r0);
+                continue;
+            }
+            gr80211_sig_desc d;
+            memset(&d, 0, sizeof(d));
+            d.mcs = (int32_t)tag_value(tags, "mcs", -1.0);
+            d.len = (int32_t)tag_value(tags, "len", -1.0);
+            d.nsamp = (int32_t)tag_value(tags, "nsamp", -1.0);
+            d.cfo = (float)tag_value(tags, "cfo", 0.0);
+            d.snr = (float)tag_value(tags, "snr", 0.0);
+            d.rssi = (float)tag_value(tags, "rssi", 0.0);
+            d.mu_pos = (uint32_t)d_muPos;
+            const tag_t *ch = tag_find(tags, "chan");
+            if (d.nsamp < 0 || d.nsamp > (1 << 24) || !ch || ch->cvec.size() < 64) {
+                d_nSeen++;
+                used++;
+                continue;
+            }
+            const size_t need = (size_t)d.nsamp + 320 + 64;
+            if (r.direct && (size_t)(at - r.base) + need > r.dev_cap) {
+                // the arena is full: this frame opens the next round
+                if (!send_span(used) || !cut()) return -1;
+                continue;
+            }
+            if (!r.direct) {
+                if (!send_span(used)) return -1;  // what came before the round's first frame is nobody's
+                const size_t cap = std::max<size_t>(need, std::min<size_t>(std::max<size_t>((size_t)d_batch * 4096, (size_t)1 << 20), (size_t)1 << 25));
+                for (int a = 0; a < d_nrx; a++) {
+                    r.dev[a] = static_cast<char *>(r.gpu->buffer(a, (cap + 64) * sizeof(gr_complex)));
+                    if (!r.dev[a]) {
+                        d_err = "device memory for the frames' items exhausted";
+                        return -1;
+                    }
+                }
+                r.dev_cap = cap;
+                r.base = at;
+                r.direct = true;
+            }
+            d_nSeen++;
+            d.off = at - r.base;
+            r.desc.push_back(d);
+            r.chan.insert(r.chan.end(), ch->cvec.begin(), ch->cvec.begin() + 64);
+            d_need = d.nsamp;
+            d_skip = 320;  // lib/demod_impl.cc:92
+            d_state = S_COLLECT;
+        }
+        if (d_state == S_COLLECT) {
+            const int take = (int)std::min<long>(d_need, n - used);
+            r.desc.back().n_avail += (uint32_t)take;
+            d_need -= take;
+            used += take;
+            if (d_need == 0) d_state = S_CLEAN;
+        }
+        if (d_state == S_CLEAN) {
+            const int take = (int)std::min<long>(d_skip, n - used);
+            d_skip -= take;
+            used += take;
+            if (d_skip == 0) {
+                d_state = S_IDLE;
+                if ((int)r.desc.size() >= d_batch && (!send_span(used) || !cut())) return -1;
+            }
+        }
+    }
+    if (!send_span(used)) return -1;
+    if (log.enqueued() < r0 + (uint64_t)used) log.set_enqueued(r0 + (uint64_t)used);
+    const int consumed = (int)(log.settled(r0) - r0);
+    consume_each(consumed);
+    return consumed;
+}
+
 // Waits for the oldest round that is still running and publishes what is ready.
 bool demod::harvest_front()
 {
@@ -1674,6 +1867,10 @@ bool demod::flush()
 {
     // a frame cut off by the end of the stream is demodulated with the items it has, like the fused block does
     d_state = S_IDLE;
+    if (d_mode == M_DIRECT && !d_up->log().drain()) {
+        d_err = "upload of the frames' items failed";
+        return false;
+    }
     if (d_fill && !cut()) return false;
     return harvest(true);
 }
@@ -1687,6 +1884,11 @@ bool demod::cut()
         return true;
     }
     if (!r.gpu->ok()) return false;
+    // the round's stream runs behind the pieces that carried its items
+    if (r.direct && !d_up->join(r.gpu->ctx())) {
+        d_err = "cannot order the round behind its uploads: " + r.gpu->error();
+        return false;
+    }
     d_nRounds++;
     r.state.store(R_RUN);
     d_flight.push_back(&r);
@@ -1709,8 +1911,9 @@ void demod::run(round &r)
         r.err = what;
         r.state.store(R_DONE);
     };
-    char *d0 = static_cast<char *>(g.buffer(0, (r.n + 64) * sizeof(gr_complex)));
-    char *d1 = d_nrx == 2 ? static_cast<char *>(g.buffer(1, (r.n + 64) * sizeof(gr_complex))) : nullptr;
+    // direct: the items are in the arena already (fill_direct); else they travel now, from the round's page-locked memory
+    char *d0 = r.direct ? r.dev[0] : static_cast<char *>(g.buffer(0, (r.n + 64) * sizeof(gr_complex)));
+    char *d1 = d_nrx != 2 ? nullptr : r.direct ? r.dev[1] : static_cast<char *>(g.buffer(1, (r.n + 64) * sizeof(gr_complex)));
     void *dch = g.buffer(2, (size_t)n * 64 * sizeof(gr_complex));
     gr80211_frame_info *dinfo = static_cast<gr80211_frame_info *>(g.buffer(3, (size_t)n * sizeof(gr80211_frame_info)));
     gr_complex *hch = static_cast<gr_complex *>(g.staging(1, (size_t)n * 64 * sizeof(gr_complex)));
@@ -1719,8 +1922,8 @@ void demod::run(round &r)
     memcpy(hch, r.chan.data(), (size_t)n * 64 * sizeof(gr_complex));
     const float *dllr = nullptr;
     uint64_t nfl = 0;
-    if (gr80211_copy_h2d_async(c, d0, r.iq[0], r.n * sizeof(gr_complex), nullptr) != GR80211_OK ||
-        (d_nrx == 2 && gr80211_copy_h2d_async(c, d1, r.iq[1], r.n * sizeof(gr_complex), nullptr) != GR80211_OK) ||
+    if ((!r.direct && (gr80211_copy_h2d_async(c, d0, r.iq[0], r.n * sizeof(gr_complex), nullptr) != GR80211_OK ||
+                       (d_nrx == 2 && gr80211_copy_h2d_async(c, d1, r.iq[1], r.n * sizeof(gr_complex), nullptr) != GR80211_OK))) ||
         gr80211_copy_h2d_async(c, dch, hch, (size_t)n * 64 * sizeof(gr_complex), nullptr) != GR80211_OK ||
         gr80211_demod_tagged_batch(c, d0, d1, r.n, r.desc.data(), n, 0, dch, dinfo, &dllr, &nfl, nullptr) != GR80211_OK ||
         gr80211_copy_d2h_async(c, hinfo, dinfo, (size_t)n * sizeof(gr80211_frame_info), nullptr) != GR80211_OK)
@@ -1737,8 +1940,12 @@ void demod::run(round &r)
         // sounding frame: the raw samples of the two VHT-LTF windows (lib/demod_impl.cc:238-249,265-271)
         std::vector<gr_complex> win(128);
         const uint64_t base = r.desc[(size_t)i].off + (uint64_t)fi.data_off + 8;
-        for (int w = 0; w < 2; w++)
-            if (base + (uint64_t)w * 80 + 64 <= r.n) memcpy(win.data() + w * 64, r.iq[0] + base + (uint64_t)w * 80, 64 * sizeof(gr_complex));
+        for (int w = 0; w < 2; w++) {
+            if (base + (uint64_t)w * 80 + 64 > r.n) continue;
+            if (!r.direct) memcpy(win.data() + w * 64, r.iq[0] + base + (uint64_t)w * 80, 64 * sizeof(gr_complex));
+            else if (gr80211_copy_d2h(c, win.data() + w * 64, d0 + (base + (uint64_t)w * 80) * sizeof(gr_complex), 64 * sizeof(gr_complex), nullptr) != GR80211_OK)
+                return fail(g.error());
+        }
         r.ndp.push_back(std::move(win));
     }
     r.state.store(R_DONE);

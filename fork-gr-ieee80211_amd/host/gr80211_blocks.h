@@ -520,6 +520,12 @@ private:
         std::unique_ptr<gpu_session> gpu;
         gr_complex *iq[2] = {nullptr, nullptr};  // page-locked: the frames' items back to back
         size_t cap = 0, n = 0;                   // items they can hold / hold
+        // input windows in page-locked memory: the items go to the device arena as they arrive and the arena mirrors
+        // the stream from `base` (the round's first frame) on
+        bool direct = false;
+        char *dev[2] = {nullptr, nullptr};
+        size_t dev_cap = 0;                      // items the arena can hold
+        uint64_t base = 0;
         std::vector<gr80211_sig_desc> desc;      // one per frame
         std::vector<gr_complex> chan;            // 64 per frame
         std::vector<gr80211_frame_info> info;    // results: one record per frame ...
@@ -532,6 +538,7 @@ private:
     };
     enum { R_FREE = 0, R_FILL, R_RUN, R_DONE, R_DRAIN };
     bool grow(round &r, size_t items);
+    int fill_direct(int n, gr_vector_const_void_star &input_items);
     bool cut();                  // the round being filled goes to its worker; another one is filled (if one is free)
     void run(round &r);          // worker thread: everything that waits for the GPU
     bool harvest(bool wait);     // publish finished rounds in order; wait: for every round in flight
@@ -547,6 +554,8 @@ private:
     enum { S_IDLE, S_COLLECT, S_CLEAN } d_state = S_IDLE;
     long d_need = 0, d_skip = 0;            // items of the current frame still to collect / to pass over
     out_stream d_out;
+    std::unique_ptr<uploader> d_up;          // the way of page-locked input windows to the GPU
+    enum { M_UNKNOWN, M_STAGED, M_DIRECT } d_mode = M_UNKNOWN;  // decided by the first window
     uint64_t d_nSeen = 0, d_nRounds = 0;
     double d_tHarvest = 0, d_tTags = 0, d_tCopyIn = 0, d_tPop = 0, d_tOther = 0;  // GR80211_BLOCK_PROFILE: where the host time goes
 };

@@ -630,23 +630,26 @@ def test_streaming_abi_from_plain_c(tmp_path, oracle, n_rx, chunk, batch):
     assert stat == "STAT pdus=%d" % len(want)
 
 
-def test_pump_chain_on_three_threads_equals_one_thread(pkg, tmp_path):
+@pytest.mark.parametrize("n_rx,chunk,batch", [(1, 3000, 7), (1, 777, 2), (1, 65536, 1000), (2, 1500, 3)])
+def test_pump_chain_on_three_threads_equals_one_thread(pkg, tmp_path, oracle, n_rx, chunk, batch):
     """gr80211_pump chaint (signal, demod and decode on a thread each, ring buffers between them, as GNU Radio's
-    scheduler runs a flowgraph) publishes the messages of gr80211_pump chain (the same blocks called in turn), in
-    the same order, with page-locked and with ordinary buffers."""
+    scheduler runs a flowgraph) publishes the messages of gr80211_pump chain (the same blocks called in turn) and of
+    the model of the reference's chain, in the same order, with page-locked buffers (demod then takes its frames'
+    items straight from the window) and with ordinary ones (it collects them first)."""
     import subprocess
-    iq0, triggers, frames = siso_stream(0.002, 40)
-    f_iq, f_tr = str(tmp_path / "iq.bin"), str(tmp_path / "tr.txt")
-    iq0.astype(np.complex64).tofile(f_iq)
-    with open(f_tr, "w") as fh:
-        for pos, rad in sorted(triggers):
-            fh.write("%d %.9g 30.0 -40.0\n" % (pos, rad))
-    pump = os.path.join(ROOT, "fork-gr-ieee80211_amd", "gr80211_pump")
+    if n_rx == 1:
+        iq0, triggers, frames = siso_stream(0.002, 40)
+        iq1 = None
+    else:
+        iq0, iq1, triggers, frames = mimo_stream(41)
+    want, n_frames = model_chain(oracle, iq0, iq1, triggers)
+    tf, files = write_stream(tmp_path, iq0, iq1, sorted(triggers))
     outs = {}
     for mode, pin in (("chain", "1"), ("chaint", "1"), ("chaint", "0")):
-        r = subprocess.run([pump, mode, "1", "3000", "7", f_tr, f_iq], capture_output=True, text=True, timeout=300,
-                           env=dict(os.environ, GR80211_PUMP_PIN=pin))
+        r = subprocess.run([PUMP, mode, str(n_rx), str(chunk), str(batch), str(tf)] + [str(f) for f in files],
+                           capture_output=True, text=True, timeout=300, env=dict(os.environ, GR80211_PUMP_PIN=pin))
         assert r.returncode == 0, r.stderr[-2000:]
-        outs[(mode, pin)] = [l for l in r.stdout.splitlines() if l.startswith("PDU ") or l.startswith("STAT")]
-    assert len(outs[("chain", "1")]) > 5
-    assert outs[("chaint", "1")] == outs[("chain", "1")] and outs[("chaint", "0")] == outs[("chain", "1")]
+        outs[(mode, pin)] = [bytes.fromhex(l.split()[1]) for l in r.stdout.splitlines() if l.startswith("PDU ")]
+    assert len(want) > 3
+    assert outs[("chain", "1")] == want
+    assert outs[("chaint", "1")] == want and outs[("chaint", "0")] == want
