@@ -11,11 +11,11 @@ cd "$(dirname "$0")/.."
 mkdir -p tools/san_tmp
 cd fork-gr-ieee80211_amd/host
 g++ -O1 -g -std=c++17 -fsanitize=address,undefined -fno-omit-frame-pointer -fno-sanitize-recover=undefined \
-    -static-libasan -static-libubsan pump.cpp gr80211_blocks.cpp host_api.cpp \
+    -static-libasan -static-libubsan -pthread pump.cpp gr80211_blocks.cpp host_api.cpp \
     -o ../../tools/san_tmp/gr80211_pump_san -L.. -lgr80211_rx -Wl,-rpath,'$ORIGIN/../../fork-gr-ieee80211_amd'
 gcc -O1 -g -std=c99 -fsanitize=address,undefined -fno-omit-frame-pointer -fno-sanitize-recover=undefined \
     -I../../include -c abi_chain.c -o ../../tools/san_tmp/abi_chain.o
 g++ -O1 -g -std=c++17 -fsanitize=address,undefined -fno-omit-frame-pointer -fno-sanitize-recover=undefined \
-    -static-libasan -static-libubsan ../../tools/san_tmp/abi_chain.o gr80211_blocks.cpp host_api.cpp \
+    -static-libasan -static-libubsan -pthread ../../tools/san_tmp/abi_chain.o gr80211_blocks.cpp host_api.cpp \
     -o ../../tools/san_tmp/gr80211_abi_chain_san -L.. -lgr80211_rx -Wl,-rpath,'$ORIGIN/../../fork-gr-ieee80211_amd'
 echo built tools/san_tmp/gr80211_pump_san tools/san_tmp/gr80211_abi_chain_san
