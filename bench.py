@@ -27,10 +27,11 @@ import sys
 import time
 
 # Streams that share a hardware queue run one after the other, and a process gets four queues unless it asks for
-# more: six contexts' streams, the collective's and the default stream want one each.  Read by the HIP runtime when
-# it starts, hence set before torch is imported.  GR80211_BENCH_HW_QUEUES=<n> asks for another number, 0 leaves
-# the environment as it is.
-_q = int(os.environ.get("GR80211_BENCH_HW_QUEUES", "8") or 0)
+# more: six contexts' streams, the collective's (RCCL brings its own) and the default stream want one each, and with
+# eight the collective's stream was seen to share one with a context's stream (12.8 instead of 10.5 ms per step once
+# the contexts wait for each other's pooled buffers).  Read by the HIP runtime when it starts, hence set before torch
+# is imported.  GR80211_BENCH_HW_QUEUES=<n> asks for another number, 0 leaves the environment as it is.
+_q = int(os.environ.get("GR80211_BENCH_HW_QUEUES", "16") or 0)
 if _q > 0:
     os.environ["GPU_MAX_HW_QUEUES"] = str(min(_q, 32))
 
