@@ -427,6 +427,8 @@ bool device_fifo::release_front(size_t items)
     return true;
 }
 
+static void copy_past_cache(void *dst, const void *src, size_t n);
+
 // GR80211_COPY_PAST_CACHE=0 switches the streaming stores of copy_past_cache off (A/B measurements).
 static bool getenv_flag_copy_past_cache()
 {
@@ -470,11 +472,155 @@ void out_stream::push_ref(const void *src, size_t items, size_t *left)
     d_pushed += items;
 }
 
+void out_stream::push_dev(gpu_session *g, const void *dev_src, size_t items, size_t *left)
+{
+    if (items == 0) return;
+    push_ref(dev_src, items, left);
+    d_segs.back().dev = g;
+}
+
+bool out_stream::flight::arrived(bool wait)
+{
+    for (auto &m : markers)
+        if (gr80211_marker_done(m.first->ctx(), m.second, wait ? 1 : 0) != 1) return false;
+    return true;
+}
+
+void out_stream::flight::settle()
+{
+    for (auto &l : lefts)
+        if (l.first) *l.first -= l.second;
+    lefts.clear();
+    markers.clear();
+}
+
+bool out_stream::pop_launch(void *dst, int max_items, flight &f, std::string &err)
+{
+    f = flight();
+    const size_t n = std::min<size_t>(pending(), max_items > 0 ? (size_t)max_items : 0);
+    if (n == 0) return true;
+    uint8_t *d = static_cast<uint8_t *>(dst);
+    size_t want = n * d_item;
+    // a run of device items that lie back to back travels as one copy
+    gpu_session *run_g = nullptr;
+    const uint8_t *run_src = nullptr;
+    uint8_t *run_dst = nullptr;
+    size_t run_bytes = 0;
+    auto flush_run = [&]() -> bool {
+        if (!run_g || !run_bytes) return true;
+        if (gr80211_push_d2h(run_g->ctx(), run_dst, run_src, run_bytes, nullptr) != GR80211_OK) {
+            err = "copy of produced items failed: " + run_g->error();
+            return false;
+        }
+        if (f.markers.empty() || f.markers.back().first != run_g) f.markers.emplace_back(run_g, -1);
+        run_bytes = 0;
+        return true;
+    };
+    while (want > 0) {
+        seg &g = d_segs.front();
+        const size_t take = std::min(want, g.bytes - g.head);
+        if (g.dev) {
+            const uint8_t *src = g.ext + g.head;
+            if (run_g != g.dev || src != run_src + run_bytes) {
+                if (!flush_run()) return false;
+                run_g = g.dev, run_src = src, run_dst = d;
+            }
+            run_bytes += take;
+        } else if (g.ext) {
+            copy_past_cache(d, g.ext + g.head, take);
+        } else {
+            memcpy(d, g.own.data() + g.head, take);
+        }
+        if (g.left) f.lefts.emplace_back(g.left, take / d_item);
+        g.head += take;
+        d += take;
+        want -= take;
+        if (g.head == g.bytes) d_segs.pop_front();
+    }
+    if (!flush_run()) return false;
+    for (auto &m : f.markers) {
+        m.second = gr80211_marker_record(m.first->ctx(), nullptr);
+        if (m.second < 0) {
+            err = "marker: " + m.first->error();
+            return false;
+        }
+    }
+    while (!d_tags.empty() && d_tags.front().offset < d_popped + n) {
+        tag_t t = d_tags.front();
+        t.offset -= d_popped;
+        f.tags.push_back(t);
+        d_tags.pop_front();
+    }
+    d_popped += n;
+    f.dst = dst;
+    f.items = n;
+    return true;
+}
+
+int direct_out::work(out_stream *const *q, void *const *dst, const uint64_t *written, int n_ports, size_t item, int noutput_items,
+                     bool must_progress, const std::function<void(int, const tag_t &)> &tag, std::string &err)
+{
+    int produced = 0;
+    auto deliver = [&]() {
+        stretch &st = d_sent.front();
+        for (int p = 0; p < n_ports; p++) {
+            out_stream::flight &f = st.f[p];
+            f.arrived(true);
+            uint8_t *here = static_cast<uint8_t *>(dst[p]) + (size_t)produced * item;
+            if (f.dst != here) memcpy(here, f.dst, st.items * item);  // the buffer wrapped since the stretch left
+            for (tag_t &t : f.tags) {
+                t.offset += written[p] + (uint64_t)produced;
+                tag(p, t);
+            }
+            f.settle();
+        }
+        produced += (int)st.items;
+        d_items -= st.items;
+        d_sent.pop_front();
+    };
+    auto arrived = [&](stretch &st) {
+        for (int p = 0; p < n_ports; p++)
+            if (!st.f[p].arrived(false)) return false;
+        return true;
+    };
+    auto launch = [&]() -> bool {
+        // half the room at a time while nothing else travels, so that the next call finds something to report while the
+        // other half is on its way
+        const size_t room = (size_t)noutput_items - (size_t)produced - d_items;
+        size_t n = std::min(room, q[0]->pending());
+        if (d_sent.empty() && n >= 16384) n = (n / 2 + 3) & ~(size_t)3;
+        if (n == 0) return true;
+        stretch st;
+        for (int p = 0; p < n_ports; p++) {
+            uint8_t *to = static_cast<uint8_t *>(dst[p]) + ((size_t)produced + d_items) * item;
+            if (!q[p]->pop_launch(to, (int)n, st.f[p], err)) return false;
+        }
+        st.items = st.f[0].items;
+        d_items += st.items;
+        d_sent.push_back(std::move(st));
+        return true;
+    };
+    while (!d_sent.empty() && (size_t)produced + d_sent.front().items <= (size_t)noutput_items && arrived(d_sent.front())) deliver();
+    if (d_sent.size() < 2 && (size_t)produced + d_items < (size_t)noutput_items && q[0]->pending() && !launch()) return -1;
+    if (produced == 0 && must_progress && !d_sent.empty() && d_sent.front().items <= (size_t)noutput_items) {
+        deliver();  // waits for it
+        if (d_sent.size() < 2 && (size_t)produced + d_items < (size_t)noutput_items && q[0]->pending() && !launch()) return -1;
+    }
+    return produced;
+}
+
 void out_stream::release_refs(const void *lo, const void *hi)
 {
     for (seg &g : d_segs) {
         if (!g.ext || g.ext < static_cast<const uint8_t *>(lo) || g.ext >= static_cast<const uint8_t *>(hi)) continue;
-        g.own.assign(g.ext + g.head, g.ext + g.bytes);
+        if (g.dev) {
+            // device memory about to be rewritten: what has not left comes back now (waits)
+            g.own.resize(g.bytes - g.head);
+            (void)gr80211_copy_d2h(g.dev->ctx(), g.own.data(), g.ext + g.head, g.bytes - g.head, nullptr);
+            g.dev = nullptr;
+        } else {
+            g.own.assign(g.ext + g.head, g.ext + g.bytes);
+        }
         g.bytes -= g.head;
         g.head = 0;
         g.ext = nullptr;
@@ -526,7 +672,8 @@ int out_stream::pop(void *dst, int max_items, uint64_t written, std::vector<tag_
     while (want > 0) {
         seg &g = d_segs.front();
         const size_t take = std::min(want, g.bytes - g.head);
-        if (g.ext) copy_past_cache(d, g.ext + g.head, take);
+        if (g.dev) (void)gr80211_copy_d2h(g.dev->ctx(), d, g.ext + g.head, take, nullptr);  // waits
+        else if (g.ext) copy_past_cache(d, g.ext + g.head, take);
         else memcpy(d, g.own.data() + g.head, take);
         g.head += take;
         d += take;
@@ -1418,7 +1565,7 @@ signal::signal(int n_rx, int batch_frames, int device)
 void signal::forecast(int noutput_items, gr_vector_int &ninput_items_required)
 {
     // items held back for lack of room need no input to leave
-    for (int &v : ninput_items_required) v = d_out0.pending() ? 0 : noutput_items;
+    for (int &v : ninput_items_required) v = (d_out0.pending() || d_direct.in_flight()) ? 0 : noutput_items;
 }
 
 int signal::general_work(int noutput_items, gr_vector_int &ninput_items, gr_vector_const_void_star &input_items,
@@ -1428,6 +1575,21 @@ int signal::general_work(int noutput_items, gr_vector_int &ninput_items, gr_vect
     const int n = d_out0.pending() > OUT_QUEUE_LIMIT ? 0 : take_input(ninput_items, input_items);
     consume_each(n < 0 ? 0 : n);
     if ((int)output_items.size() < d_nrx) return 0;
+    if (d_outMode == 0 && noutput_items > 0) {
+        bool pinned = true;
+        for (int a = 0; a < d_nrx; a++) pinned = pinned && is_pinned(output_items[(size_t)a], (size_t)noutput_items * sizeof(gr_complex));
+        bool direct = pinned && (size_t)noutput_items * sizeof(gr_complex) >= 2 * DIRECT_OUT_MIN_BYTES;
+        if (const char *e = getenv("GR80211_SIGNAL_DIRECT_OUT")) direct = e[0] != '0' && pinned;  // experiments
+        d_outMode = direct ? 2 : 1;
+    }
+    if (d_outMode == 2) {
+        out_stream *q[2] = {&d_out0, &d_out1};
+        void *dst[2] = {output_items[0], d_nrx == 2 ? output_items[1] : nullptr};
+        const uint64_t wr[2] = {nitems_written(0), d_nrx == 2 ? nitems_written(1) : 0};
+        const int produced = d_direct.work(q, dst, wr, d_nrx, sizeof(gr_complex), noutput_items, n <= 0,
+                                           [this](int port, const tag_t &t) { if (port == 0) add_item_tag(0, t); }, d_err);
+        return produced < 0 ? 0 : produced;
+    }
     std::vector<tag_t> tags;
     const int produced = d_out0.pop(output_items[0], noutput_items, nitems_written(0), tags);
     for (const tag_t &t : tags) add_item_tag(0, t);
@@ -1469,14 +1631,17 @@ bool signal::start_frames(round &r)
         d_err = "allocation of the output buffers failed";
         return false;
     }
-    d_span[ri][0].lo = reinterpret_cast<const char *>(h0);
-    d_span[ri][0].hi = reinterpret_cast<const char *>(h0 + total) + 8;
-    d_span[ri][1].lo = reinterpret_cast<const char *>(h1);
-    d_span[ri][1].hi = h1 ? reinterpret_cast<const char *>(h1 + total) + 8 : nullptr;
+    const bool dev_out = d_outMode == 2;  // the items stay on the device until the scheduler makes room
+    d_devOut[ri] = dev_out;
+    const gr_complex *s0 = dev_out ? static_cast<const gr_complex *>(do0) : h0, *s1 = dev_out ? static_cast<const gr_complex *>(do1) : h1;
+    d_span[ri][0].lo = reinterpret_cast<const char *>(s0);
+    d_span[ri][0].hi = reinterpret_cast<const char *>(s0 + total) + 8;
+    d_span[ri][1].lo = reinterpret_cast<const char *>(s1);
+    d_span[ri][1].hi = s1 ? reinterpret_cast<const char *>(s1 + total) + 8 : nullptr;
     if (gr80211_signal_emit_batch(c, diq0, diq1, nheld, fd.data(), nf, 0, off.data(), do0, do1, total, nullptr, dch,
                                   nullptr) != GR80211_OK ||
-        gr80211_push_d2h(c, h0, do0, (size_t)total * sizeof(gr_complex), nullptr) != GR80211_OK ||
-        (d_nrx == 2 && gr80211_push_d2h(c, h1, do1, (size_t)total * sizeof(gr_complex), nullptr) != GR80211_OK) ||
+        (!dev_out && gr80211_push_d2h(c, h0, do0, (size_t)total * sizeof(gr_complex), nullptr) != GR80211_OK) ||
+        (!dev_out && d_nrx == 2 && gr80211_push_d2h(c, h1, do1, (size_t)total * sizeof(gr_complex), nullptr) != GR80211_OK) ||
         gr80211_push_d2h(c, hch, dch, (size_t)nf * 64 * sizeof(gr_complex), nullptr) != GR80211_OK) {
         d_err = d_gpu.error();
         return false;
@@ -1496,6 +1661,8 @@ bool signal::finish_frames(round &r)
     const gr_complex *h0 = static_cast<const gr_complex *>(d_gpu.staging(0, (size_t)total * sizeof(gr_complex) + 8));
     const gr_complex *h1 = d_nrx == 2 ? static_cast<const gr_complex *>(d_gpu.staging(1, (size_t)total * sizeof(gr_complex) + 8)) : nullptr;
     const gr_complex *hch = static_cast<const gr_complex *>(d_gpu.staging(3, (size_t)nf * 64 * sizeof(gr_complex)));
+    const gr_complex *do0 = static_cast<const gr_complex *>(d_gpu.buffer(3, (size_t)(total + 64) * sizeof(gr_complex)));
+    const gr_complex *do1 = d_nrx == 2 ? static_cast<const gr_complex *>(d_gpu.buffer(4, (size_t)(total + 64) * sizeof(gr_complex))) : nullptr;
     for (int i = 0; i < nf; i++) {
         const frame_ref &r = fr[(size_t)i];
         // lib/signal_impl.cc:133-152: the tags sit on the frame's first output item
@@ -1514,6 +1681,11 @@ bool signal::finish_frames(round &r)
         t.cvec.assign(hch + (size_t)i * 64, hch + (size_t)i * 64 + 64);
         d_out0.tag(t);
         const size_t cnt = (size_t)r.nsamp + 320;
+        if (d_devOut[ri]) {
+            d_out0.push_dev(&d_gpu, do0 + off[(size_t)i], cnt, &d_left[ri]);
+            if (d_nrx == 2) d_out1.push_dev(&d_gpu, do1 + off[(size_t)i], cnt, &d_left[ri]);
+            continue;
+        }
         d_out0.push_ref(h0 + off[(size_t)i], cnt, &d_left[ri]);
         if (d_nrx == 2) d_out1.push_ref(h1 + off[(size_t)i], cnt, &d_left[ri]);
     }
@@ -1558,7 +1730,7 @@ demod::~demod()
 void demod::forecast(int noutput_items, gr_vector_int &ninput_items_required)
 {
     // lib/demod_impl.cc:53-57; soft bits held back for lack of room need no input to leave
-    for (int &v : ninput_items_required) v = d_out.pending() ? 0 : noutput_items;
+    for (int &v : ninput_items_required) v = (d_out.pending() || d_direct.in_flight()) ? 0 : noutput_items;
 }
 
 demod::round *demod::free_round()
@@ -1711,16 +1883,41 @@ int demod::general_work(int noutput_items, gr_vector_int &ninput_items, gr_vecto
     if (output_items.empty()) return 0;
     tags.clear();
     lap(d_tOther);
-    int produced = d_out.pop(output_items[0], noutput_items, nitems_written(0), tags);
-    lap(d_tPop);
-    if (used == 0 && produced == 0 && n > 0 && noutput_items > 0 && !d_flight.empty()) {
-        // Neither input taken (every round is on its way) nor output to give: the one case in which the call waits,
-        // for the oldest round, so that a caller never sees a call without progress while work is in flight (a
-        // scheduler would read that as the end of the stream).
-        if (!harvest_front()) return 0;
-        produced = d_out.pop(output_items[0], noutput_items, nitems_written(0), tags);
+    if (d_outMode.load() == 0 && noutput_items > 0) {
+        // decided by the first output buffer: soft bits travel from the device straight into page-locked buffers
+        // (buffers that take a megabyte at a time: below that a call's share of launches and completion queries costs
+        // more than copying the items by hand, 250 against 285 Msamples/s through the three-block chain at 256-KB windows)
+        bool direct = (size_t)noutput_items * sizeof(float) >= DIRECT_OUT_MIN_BYTES &&
+                      is_pinned(output_items[0], (size_t)noutput_items * sizeof(float));
+        if (const char *e = getenv("GR80211_DEMOD_DIRECT_OUT")) direct = e[0] != '0' && is_pinned(output_items[0], (size_t)noutput_items * sizeof(float));  // experiments
+        d_outMode.store(direct ? 2 : 1);
     }
-    for (const tag_t &t : tags) add_item_tag(0, t);
+    int produced = 0;
+    if (d_outMode.load() == 2) {
+        out_stream *q[1] = {&d_out};
+        void *dst[1] = {output_items[0]};
+        const uint64_t wr[1] = {nitems_written(0)};
+        const auto tagger = [this](int port, const tag_t &t) { add_item_tag(port, t); };
+        produced = d_direct.work(q, dst, wr, 1, sizeof(float), noutput_items, used == 0, tagger, d_err);
+        if (produced < 0) return 0;
+        if (used == 0 && produced == 0 && n > 0 && noutput_items > 0 && !d_flight.empty() && d_direct.in_flight() == 0) {
+            // neither input taken nor output to give while rounds are on their way: wait for the oldest (see below)
+            if (!harvest_front()) return 0;
+            produced = d_direct.work(q, dst, wr, 1, sizeof(float), noutput_items, true, tagger, d_err);
+            if (produced < 0) return 0;
+        }
+    } else {
+        produced = d_out.pop(output_items[0], noutput_items, nitems_written(0), tags);
+        if (used == 0 && produced == 0 && n > 0 && noutput_items > 0 && !d_flight.empty()) {
+            // Neither input taken (every round is on its way) nor output to give: the one case in which the call waits,
+            // for the oldest round, so that a caller never sees a call without progress while work is in flight (a
+            // scheduler would read that as the end of the stream).
+            if (!harvest_front()) return 0;
+            produced = d_out.pop(output_items[0], noutput_items, nitems_written(0), tags);
+        }
+        for (const tag_t &t : tags) add_item_tag(0, t);
+    }
+    lap(d_tPop);
     // rounds whose soft bits have all left are free again
     while (!d_flight.empty() && d_flight.front()->state.load() == R_DRAIN && d_flight.front()->left == 0) {
         d_flight.front()->state.store(R_FREE);
@@ -1928,10 +2125,19 @@ void demod::run(round &r)
         gr80211_demod_tagged_batch(c, d0, d1, r.n, r.desc.data(), n, 0, dch, dinfo, &dllr, &nfl, nullptr) != GR80211_OK ||
         gr80211_copy_d2h_async(c, hinfo, dinfo, (size_t)n * sizeof(gr80211_frame_info), nullptr) != GR80211_OK)
         return fail(g.error());
-    float *llr = static_cast<float *>(g.staging(0, (size_t)(nfl + 1) * sizeof(float)));
-    if (!llr) return fail("page-locked host memory exhausted");
-    if ((nfl && gr80211_copy_d2h_async(c, llr, dllr, (size_t)nfl * sizeof(float), nullptr) != GR80211_OK) || !g.sync())
-        return fail(g.error());
+    // the soft bits either come back to page-locked memory of the round now, or stay on the device and travel into the
+    // scheduler's buffer when it makes room (d_outMode 2)
+    float *llr = nullptr;
+    r.llr_dev = nullptr;
+    if (d_outMode.load() == 2) {
+        r.llr_dev = dllr;
+        if (!g.sync()) return fail(g.error());
+    } else {
+        llr = static_cast<float *>(g.staging(0, (size_t)(nfl + 1) * sizeof(float)));
+        if (!llr) return fail("page-locked host memory exhausted");
+        if ((nfl && gr80211_copy_d2h_async(c, llr, dllr, (size_t)nfl * sizeof(float), nullptr) != GR80211_OK) || !g.sync())
+            return fail(g.error());
+    }
     memcpy(r.info.data(), hinfo, (size_t)n * sizeof(gr80211_frame_info));
     r.llr = llr;
     for (int i = 0; i < n; i++) {
@@ -1998,7 +2204,8 @@ bool demod::harvest(bool wait)
                 continue;
             }
             t.key = "total";   t.value = (double)fi.total; d_out.tag(t);
-            d_out.push_ref(r.llr + fi.llr_off, (size_t)fi.total, &r.left);
+            if (r.llr_dev) d_out.push_dev(r.gpu.get(), r.llr_dev + fi.llr_off, (size_t)fi.total, &r.left);
+            else d_out.push_ref(r.llr + fi.llr_off, (size_t)fi.total, &r.left);
         }
         r.state.store(R_DRAIN);
     }

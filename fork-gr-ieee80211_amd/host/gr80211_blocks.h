@@ -90,6 +90,9 @@ public:
     void *alloc_input(size_t bytes);
     void free_input(void *p);
     bool pin_input(const void *p, size_t bytes);
+    // a buffer somebody else made page-locked (e.g. the input buffer of the block downstream, which is this block's
+    // output buffer): items may then travel to it straight from the GPU
+    void declare_pinned(const void *p, size_t bytes) { if (p && bytes) d_pinned.emplace_back(static_cast<const char *>(p), bytes); }
 
 protected:
     explicit block(int n_in, int n_out = 0);
@@ -247,15 +250,32 @@ public:
     void push(const void *src, size_t items);
     void push_zeros(size_t items);
     void push_ref(const void *src, size_t items, size_t *left = nullptr);
+    // items that stay in device memory of `g`'s context until they leave (kept untouched by the caller like push_ref's)
+    void push_dev(gpu_session *g, const void *dev_src, size_t items, size_t *left = nullptr);
     // referenced items that lie in [lo, hi) are copied, so that the memory may be written again
     void release_refs(const void *lo, const void *hi);
     void tag(const tag_t &t) { d_tags.push_back(t); }  // t.offset = index among the pushed items
-    // up to max_items into dst; their tags into `out`, re-based to the port's absolute offset `written`
+    // up to max_items into dst; their tags into `out`, re-based to the port's absolute offset `written` (items in
+    // device memory are copied and waited for)
     int pop(void *dst, int max_items, uint64_t written, std::vector<tag_t> &out);
+    // The same without the wait, for a dst in page-locked memory: items in device memory are sent on their way by the
+    // stream of the context that holds them (contiguous runs as one copy), the others are copied at once.  `f` says
+    // what to wait for (arrived) and what to do then (settle); until then dst belongs to the copies.
+    struct flight {
+        void *dst = nullptr;
+        size_t items = 0;
+        std::vector<std::pair<gpu_session *, long long>> markers;  // passed = the copies have landed
+        std::vector<std::pair<size_t *, size_t>> lefts;            // referenced-item counters to lower afterwards
+        std::vector<tag_t> tags;                                   // offsets relative to the first item
+        bool arrived(bool wait);
+        void settle();  // lowers the counters; the items may be reported
+    };
+    bool pop_launch(void *dst, int max_items, flight &f, std::string &err);
 
 private:
     struct seg {
         const uint8_t *ext = nullptr;  // referenced items (nullptr: own holds them)
+        gpu_session *dev = nullptr;    // ext is an address in this context's device memory
         std::vector<uint8_t> own;
         size_t bytes = 0, head = 0;    // size and what has left
         size_t *left = nullptr;
@@ -264,6 +284,31 @@ private:
     std::deque<seg> d_segs;
     uint64_t d_pushed = 0, d_popped = 0;
     std::deque<tag_t> d_tags;
+};
+
+// Produced items on their way from device memory into output buffers in page-locked memory (one or two ports that
+// always carry the same item counts).  A call reports the stretches that have arrived and sends the next one on its
+// way behind those still travelling; a stretch lies where the scheduler's write pointer will be once everything before
+// it has been reported (after the buffer wrapped: where it would have been, and is moved).  Up to two stretches travel
+// at a time, so that the link is busy while the scheduler takes the one before.
+constexpr size_t DIRECT_OUT_MIN_BYTES = (size_t)1 << 20;  // output windows from which on items travel directly
+class direct_out
+{
+public:
+    size_t in_flight() const { return d_items; }
+    // q / dst / written: per port; tag(port, t): the block's add_item_tag.  must_progress: the call has taken no input,
+    // so it waits for the oldest stretch rather than report nothing.  Returns items produced (every port the same), -1
+    // on an error.
+    int work(out_stream *const *q, void *const *dst, const uint64_t *written, int n_ports, size_t item, int noutput_items,
+             bool must_progress, const std::function<void(int, const tag_t &)> &tag, std::string &err);
+
+private:
+    struct stretch {
+        out_stream::flight f[2];
+        size_t items = 0;
+    };
+    std::deque<stretch> d_sent;
+    size_t d_items = 0;
 };
 
 // What the reference flowgraphs connect to decode's "out" port: a network.socket_pdu block of type UDP_CLIENT
@@ -466,7 +511,7 @@ public:
     void forecast(int noutput_items, gr_vector_int &ninput_items_required) override;
     int general_work(int noutput_items, gr_vector_int &ninput_items, gr_vector_const_void_star &input_items,
                      gr_vector_void_star &output_items) override;
-    size_t pending_output() const { return d_out0.pending(); }
+    size_t pending_output() const { return d_out0.pending() + d_direct.in_flight(); }
 
 protected:
     signal(int n_rx, int batch_frames, int device);
@@ -483,7 +528,12 @@ private:
     size_t d_left[N_ROUNDS] = {};           // per round: items the output queues still reference
     struct span {
         const char *lo = nullptr, *hi = nullptr;
-    } d_span[N_ROUNDS][2];                  // per round and antenna: the page-locked memory they lie in
+    } d_span[N_ROUNDS][2];                  // per round and antenna: the memory they lie in (page-locked, or the device's)
+    // output buffers in page-locked memory (decided by the first one offered): a round's items stay on the device and
+    // travel into the scheduler's buffers directly
+    int d_outMode = 0;                      // 0 undecided, 1 through page-locked memory of the round, 2 direct
+    bool d_devOut[N_ROUNDS] = {};           // per round: its items were left on the device
+    direct_out d_direct;
 };
 
 // ieee80211::demod(mupos, mugid) (n_rx = 1: in {c64}) and demod2 (n_rx = 2: in {c64, c64}), out {f32},
@@ -501,7 +551,7 @@ public:
     int general_work(int noutput_items, gr_vector_int &ninput_items, gr_vector_const_void_star &input_items,
                      gr_vector_void_star &output_items) override;
     bool flush() override;
-    size_t pending_output() const { return d_out.pending(); }
+    size_t pending_output() const { return d_out.pending() + d_direct.in_flight(); }
     uint64_t frames_seen() const { return d_nSeen; }
     uint64_t rounds_cut() const { return d_nRounds; }
     void set_mu_pos(int pos) { d_muPos = pos ? 1 : 0; }
@@ -529,7 +579,8 @@ private:
         std::vector<gr80211_sig_desc> desc;      // one per frame
         std::vector<gr_complex> chan;            // 64 per frame
         std::vector<gr80211_frame_info> info;    // results: one record per frame ...
-        const float *llr = nullptr;              // ... and the soft bits, page-locked
+        const float *llr = nullptr;              // ... and the soft bits, page-locked,
+        const float *llr_dev = nullptr;          // or (output buffers in page-locked memory) still on the device
         std::vector<std::vector<gr_complex>> ndp;  // raw VHT-LTF windows of sounding frames, in frame order
         std::thread worker;
         std::atomic<int> state{0};               // FREE, FILL, RUN, DONE (results there), DRAIN (soft bits leaving)
@@ -554,6 +605,11 @@ private:
     enum { S_IDLE, S_COLLECT, S_CLEAN } d_state = S_IDLE;
     long d_need = 0, d_skip = 0;            // items of the current frame still to collect / to pass over
     out_stream d_out;
+    // Output buffers in page-locked memory: a round's soft bits stay on the device and travel into the scheduler's
+    // buffer directly.  A call sends the next stretch on its way behind the items it reports and reports that stretch
+    // when called again (the scheduler's write pointer has then moved to exactly where it lies).
+    std::atomic<int> d_outMode{0};           // 0 undecided, 1 through page-locked memory of the round, 2 direct
+    direct_out d_direct;                     // the stretches on their way
     std::unique_ptr<uploader> d_up;          // the way of page-locked input windows to the GPU
     enum { M_UNKNOWN, M_STAGED, M_DIRECT } d_mode = M_UNKNOWN;  // decided by the first window
     uint64_t d_nSeen = 0, d_nRounds = 0;

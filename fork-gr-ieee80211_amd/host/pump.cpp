@@ -501,6 +501,10 @@ static int run(int argc, char **argv)
             out_sg.push_back(&l_s1);
             in_dm.push_back(&l_s1);
         }
+        // a block's output buffer is the next block's input buffer: tell the producer when it is page-locked
+        for (ring_link *l : {&l_s0, &l_s1})
+            if (l->owner) sg->declare_pinned(l->buf, (l->cap + l->win) * l->item);
+        if (l_llr.owner) dm->declare_pinned(l_llr.buf, (l_llr.cap + l_llr.win) * l_llr.item);
         std::atomic<bool> failed{false};
         const auto t0 = std::chrono::steady_clock::now();
         std::thread t_sg(run_block, sg.get(), in_sg, out_sg, chunk, &failed, "signal");

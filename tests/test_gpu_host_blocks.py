@@ -645,11 +645,16 @@ def test_pump_chain_on_three_threads_equals_one_thread(pkg, tmp_path, oracle, n_
     want, n_frames = model_chain(oracle, iq0, iq1, triggers)
     tf, files = write_stream(tmp_path, iq0, iq1, sorted(triggers))
     outs = {}
-    for mode, pin in (("chain", "1"), ("chaint", "1"), ("chaint", "0")):
+    # "direct": items also leave signal and demod straight from the device into the page-locked buffer of the block
+    # downstream (what the blocks do by themselves for windows of a megabyte and more)
+    for mode, pin in (("chain", "1"), ("chaint", "1"), ("chaint", "0"), ("chaint", "direct")):
+        env = dict(os.environ, GR80211_PUMP_PIN="0" if pin == "0" else "1")
+        if pin == "direct":
+            env.update(GR80211_DEMOD_DIRECT_OUT="1", GR80211_SIGNAL_DIRECT_OUT="1")
         r = subprocess.run([PUMP, mode, str(n_rx), str(chunk), str(batch), str(tf)] + [str(f) for f in files],
-                           capture_output=True, text=True, timeout=300, env=dict(os.environ, GR80211_PUMP_PIN=pin))
+                           capture_output=True, text=True, timeout=300, env=env)
         assert r.returncode == 0, r.stderr[-2000:]
         outs[(mode, pin)] = [bytes.fromhex(l.split()[1]) for l in r.stdout.splitlines() if l.startswith("PDU ")]
     assert len(want) > 3
     assert outs[("chain", "1")] == want
-    assert outs[("chaint", "1")] == want and outs[("chaint", "0")] == want
+    assert outs[("chaint", "1")] == want and outs[("chaint", "0")] == want and outs[("chaint", "direct")] == want
