@@ -79,6 +79,13 @@ int gr80211_block_pin_input(gr80211_block *b, const void *p, uint64_t bytes)
     return b->b->pin_input(p, (size_t)bytes) ? 0 : -1;
 }
 
+int gr80211_block_declare_pinned(gr80211_block *b, const void *p, uint64_t bytes)
+{
+    if (!b || !p || !bytes) return -1;
+    b->b->declare_pinned(p, (size_t)bytes);
+    return 0;
+}
+
 int gr80211_block_send_udp(gr80211_block *b, const char *host, int port)
 {
     if (!b) return -1;

@@ -17,7 +17,7 @@ EXPORTS = ("gr80211_block_create", "gr80211_block_destroy", "gr80211_block_set_m
            "gr80211_block_set_option", "gr80211_block_n_inputs", "gr80211_block_forecast", "gr80211_block_work",
            "gr80211_block_flush", "gr80211_block_last_error", "gr80211_block_n_outputs", "gr80211_block_work_out",
            "gr80211_block_pending_output", "gr80211_block_alloc_input", "gr80211_block_free_input",
-           "gr80211_block_pin_input", "gr80211_block_send_udp")
+           "gr80211_block_pin_input", "gr80211_block_declare_pinned", "gr80211_block_send_udp")
 UDP_EXPORTS = ("gr80211_udp_open", "gr80211_udp_send", "gr80211_udp_close")
 
 
@@ -67,6 +67,7 @@ def load_host_library():
     L.gr80211_block_free_input.restype = None
     L.gr80211_block_free_input.argtypes = [vp, vp]
     L.gr80211_block_pin_input.argtypes = [vp, vp, ctypes.c_uint64]
+    L.gr80211_block_declare_pinned.argtypes = [vp, vp, ctypes.c_uint64]
     L.gr80211_block_send_udp.argtypes = [vp, ctypes.c_char_p, ci]
     L.gr80211_udp_open.restype = vp
     L.gr80211_udp_open.argtypes = [ctypes.c_char_p, ci]

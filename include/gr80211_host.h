@@ -121,6 +121,17 @@ void *gr80211_block_alloc_input(gr80211_block *b, uint64_t bytes);
 void gr80211_block_free_input(gr80211_block *b, void *p);
 int gr80211_block_pin_input(gr80211_block *b, const void *p, uint64_t bytes);
 /*
+ * Page-locked output buffers.  Tells a block with stream outputs (SIGNAL, SIGNAL2, DEMOD, DEMOD2) that [p, p + bytes) --
+ * typically the input buffer of the block downstream, from that block's gr80211_block_alloc_input -- is page-locked.
+ * Into such a buffer, when it takes a megabyte or more at a time, produced items travel from the GPU directly: a call
+ * sends the next stretch on its way behind the items it reports (inside the noutput_items it was offered, beyond what
+ * it returns) and reports the stretch when called again, at the position the scheduler's write pointer has then
+ * reached (lib/signal_impl.cc:164-202 and lib/demod_impl.cc:279-330 write their items inside general_work instead).
+ * The caller must therefore offer output space that does not shrink or move by more than the items reported; a ring
+ * buffer that wraps is handled (the stretch is moved).  0 on success.
+ */
+int gr80211_block_declare_pinned(gr80211_block *b, const void *p, uint64_t bytes);
+/*
  * The UDP hand-off of the reference flowgraphs: decode's "out" port feeds a network.socket_pdu block of type
  * UDP_CLIENT (examples/cmu_v3/trxSta0.grc:301-313,1054; 127.0.0.1:9527), which sends every PDU's blob --
  * [format][len lo][len hi][payload][mcs] -- as one datagram.  gr80211_block_send_udp makes the block do the same
