@@ -586,7 +586,7 @@ def main():
                     help="work sets (soft bits, survivor words, decoded bits) the rotating contexts share "
                          "(gr80211_use_work_pool: that many survivor buffers and two soft-bit buffers more); 0 = every context its "
                          "own; -1 = two when more than three contexts rotate "
-                         "and their own buffers would take more than 48 GB together")
+                         "and their own buffers would take more than 64 GB together")
     ap.add_argument("--latency", type=int, default=1, help="also time small batches one at a time (0 = skip)")
     ap.add_argument("--force-collective", action="store_true",
                     help="N = 1: run the exchange step all the same (process group of one rank, the gather of the MPDUs on "
@@ -674,7 +674,7 @@ def main():
         pool = 0
     else:
         # what one context's work buffers take for this batch decides: six sets of a small batch are cheap and let six
-        # batches overlap, six of the headline batch would hold 100 GB
+        # batches overlap (up to 64 GB of them are left alone), six of the headline batch would hold 100 GB
         probe = pkg.RxContext(local)
         for a0, a1, d_, npart, _, _ in parts:
             probe.rx_batch(a0, a1, d_, npart, out_stride=out_stride, want_info=False)
@@ -683,7 +683,7 @@ def main():
         probe.close()
         del probe
         torch.cuda.empty_cache()
-        pool = 2 if own_bytes * pipe > 48e9 else 0
+        pool = 2 if own_bytes * pipe > 64e9 else 0
     rot = Rotation(torch, dist, pkg, shard, local, dev, parts, n, out_stride, pipe, collective, compact, ctx,
                    side_copy=args.side_copy and not collective, pool=pool)
     out, out_len, n_pdu = rot.outs[0]
