@@ -103,6 +103,17 @@ void block::add_item_tag_in(int port, const tag_t &t)
     tv.insert(it, t);
 }
 
+void block::add_item_tag_in(int port, tag_t &&t)
+{
+    std::deque<tag_t> &tv = d_tags[port];
+    if (tv.empty() || tv.back().offset <= t.offset) {
+        tv.push_back(std::move(t));
+        return;
+    }
+    auto it = std::upper_bound(tv.begin(), tv.end(), t.offset, [](uint64_t o, const tag_t &x) { return o < x.offset; });
+    tv.insert(it, std::move(t));
+}
+
 void block::get_tags_in_range(std::vector<tag_t> &v, int port, uint64_t start, uint64_t end) const
 {
     v.clear();

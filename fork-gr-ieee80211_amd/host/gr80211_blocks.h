@@ -68,6 +68,7 @@ public:
 
     // ---- scheduler side
     void add_item_tag_in(int port, const tag_t &t);  // any order; cheapest in non-decreasing offset order
+    void add_item_tag_in(int port, tag_t &&t);
     void clear_item_tags_in() { for (auto &tv : d_tags) tv.clear(); }
     void set_msg_handler(std::function<void(const std::string &port, const pdu_t &msg)> f) { d_handler = std::move(f); }
     uint64_t nitems_read(int port) const { return d_read[port]; }

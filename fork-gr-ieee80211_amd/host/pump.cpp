@@ -238,15 +238,15 @@ static void run_block(block *b, std::vector<ring_link *> in, std::vector<ring_li
         gr_vector_int nin(in.size(), nin_items);
         gr_vector_const_void_star ip(in.size());
         gr_vector_void_star op(out.size());
-        b->clear_item_tags_in();
+        // tags change hands once: the block keeps those of items it has not consumed yet (block::commit drops the
+        // others), so a call only brings the tags of the items that are new in its window
         for (size_t p = 0; p < in.size(); p++) {
             ip[p] = in[p]->read_ptr();
             const uint64_t r0 = in[p]->r.load(std::memory_order_relaxed);
             std::lock_guard<std::mutex> lk(in[p]->m);
-            while (!in[p]->tags.empty() && in[p]->tags.front().offset < r0) in[p]->tags.pop_front();
-            for (const tag_t &t : in[p]->tags) {
-                if (t.offset >= r0 + (uint64_t)nin_items) break;
-                b->add_item_tag_in((int)p, t);
+            while (!in[p]->tags.empty() && in[p]->tags.front().offset < r0 + (uint64_t)nin_items) {
+                if (in[p]->tags.front().offset >= r0) b->add_item_tag_in((int)p, std::move(in[p]->tags.front()));
+                in[p]->tags.pop_front();
             }
         }
         for (size_t p = 0; p < out.size(); p++) op[p] = out[p]->write_ptr();

@@ -76,7 +76,7 @@ def main():
             if not only:
                 run(["rx", 1, chunk, batch, f_tr, f_iq], ns, "rx      window %7d batch %5d" % (chunk, batch), pin)
     # the reference's three blocks as three blocks: one thread each (a flowgraph), and all on one thread
-    n_chain = min(n, 60000)
+    n_chain = min(n, int(os.environ.get("GR80211_CHAIN_FRAMES", "200000")))  # frames the three-block rows play
     f_iqc = f_iq
     if n_chain < n:
         f_iqc = os.path.join(work, "iq0_chain.bin")
@@ -88,9 +88,17 @@ def main():
     for pin in (True, False):
         for chunk, batch in ((65536, 4096), (1 << 18, 4096), (1 << 20, 8192)):
             run(["chaint", 1, chunk, batch, f_trc, f_iqc], n_chain * L, "chain, 3 threads window %7d batch %5d" % (chunk, batch), pin)
-    if n_chain <= 60000:
-        run(["chain", 1, 65536, 4096, f_trc, f_iqc], n_chain * L, "chain, 1 thread  window   65536 batch  4096")
     for f in (f_trc,) + ((f_iqc,) if f_iqc != f_iq else ()):
+        os.remove(f)
+    # the same blocks called in turn by one thread, on the first 60 000 frames (it keeps whole streams between the blocks)
+    n_one = min(n, 60000)
+    f_iq1, f_tr1 = os.path.join(work, "iq0_one.bin"), os.path.join(work, "trig_one.txt")
+    iq[: n_one * L + 64].tofile(f_iq1)
+    with open(f_tr1, "w") as fh:
+        for p in sync[:n_one].tolist():
+            fh.write("%d 0.0 30.0 -40.0\n" % p)
+    run(["chain", 1, 65536, 4096, f_tr1, f_iq1], n_one * L, "chain, 1 thread  window   65536 batch  4096")
+    for f in (f_iq1, f_tr1):
         os.remove(f)
     if not only:
         run(["capture", 1, 65536, f_iq], ns, "capture window   65536")
