@@ -245,14 +245,14 @@ void block::unpin_all()
     d_pinned.clear();
 }
 
-uint64_t upload_log::settled(uint64_t from)
+uint64_t upload_log::settled(uint64_t from, bool may_wait)
 {
     uint64_t upto = from;
     while (!d_q.empty()) {
         const entry &e = d_q.front();
         if (e.g) {
             // nothing free yet and a copy on its way: wait for it, so that every call consumes something
-            const int wait = upto == from ? 1 : 0;
+            const int wait = upto == from && may_wait ? 1 : 0;
             const auto t0 = std::chrono::steady_clock::now();
             const int done = e.pull ? gr80211_pull_done(e.g->ctx(), e.id, wait) : gr80211_marker_done(e.g->ctx(), e.id, wait);
             const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -1904,6 +1904,9 @@ int demod::general_work(int noutput_items, gr_vector_int &ninput_items, gr_vecto
         d_outMode.store(direct ? 2 : 1);
     }
     int produced = 0;
+    // pieces of input on their way: a call that has nothing else to report waits for the oldest of them (below), which
+    // takes microseconds, rather than for a round on the GPU
+    const bool uploads_pending = d_mode == M_DIRECT && !d_up->log().empty();
     if (d_outMode.load() == 2) {
         out_stream *q[1] = {&d_out};
         void *dst[1] = {output_items[0]};
@@ -1911,7 +1914,7 @@ int demod::general_work(int noutput_items, gr_vector_int &ninput_items, gr_vecto
         const auto tagger = [this](int port, const tag_t &t) { add_item_tag(port, t); };
         produced = d_direct.work(q, dst, wr, 1, sizeof(float), noutput_items, used == 0, tagger, d_err);
         if (produced < 0) return 0;
-        if (used == 0 && produced == 0 && n > 0 && noutput_items > 0 && !d_flight.empty() && d_direct.in_flight() == 0) {
+        if (used == 0 && produced == 0 && n > 0 && noutput_items > 0 && !d_flight.empty() && d_direct.in_flight() == 0 && !uploads_pending) {
             // neither input taken nor output to give while rounds are on their way: wait for the oldest (see below)
             if (!harvest_front()) return 0;
             produced = d_direct.work(q, dst, wr, 1, sizeof(float), noutput_items, true, tagger, d_err);
@@ -1919,7 +1922,7 @@ int demod::general_work(int noutput_items, gr_vector_int &ninput_items, gr_vecto
         }
     } else {
         produced = d_out.pop(output_items[0], noutput_items, nitems_written(0), tags);
-        if (used == 0 && produced == 0 && n > 0 && noutput_items > 0 && !d_flight.empty()) {
+        if (used == 0 && produced == 0 && n > 0 && noutput_items > 0 && !d_flight.empty() && !uploads_pending) {
             // Neither input taken (every round is on its way) nor output to give: the one case in which the call waits,
             // for the oldest round, so that a caller never sees a call without progress while work is in flight (a
             // scheduler would read that as the end of the stream).
@@ -1929,6 +1932,10 @@ int demod::general_work(int noutput_items, gr_vector_int &ninput_items, gr_vecto
         for (const tag_t &t : tags) add_item_tag(0, t);
     }
     lap(d_tPop);
+    if (d_mode == M_DIRECT && used == 0 && produced == 0 && !d_up->log().empty()) {
+        used = settle_direct();  // nothing else moved: wait for the oldest piece on its way
+        lap(d_tCopyIn);
+    }
     // rounds whose soft bits have all left are free again
     while (!d_flight.empty() && d_flight.front()->state.load() == R_DRAIN && d_flight.front()->left == 0) {
         d_flight.front()->state.store(R_FREE);
@@ -2055,7 +2062,17 @@ int demod::fill_direct(int n, gr_vector_const_void_star &input_items)
     }
     if (!send_span(used)) return -1;
     if (log.enqueued() < r0 + (uint64_t)used) log.set_enqueued(r0 + (uint64_t)used);
-    const int consumed = (int)(log.settled(r0) - r0);
+    // what has arrived; the caller waits for the oldest piece (settle_direct) if the call would otherwise end without
+    // progress, and not while there are soft bits to hand on
+    const int consumed = (int)(log.settled(r0, false) - r0);
+    consume_each(consumed);
+    return consumed;
+}
+
+int demod::settle_direct()
+{
+    const uint64_t r0 = nitems_read(0);
+    const int consumed = (int)(d_up->log().settled(r0, true) - r0);
     consume_each(consumed);
     return consumed;
 }

@@ -166,7 +166,7 @@ public:
     void add(gpu_session *g, long long id, uint64_t upto, bool pull = false) { d_q.push_back({g, id, upto, pull}); }
     // absolute index up to which items may be consumed, at least `from`; waits for the oldest copy if nothing beyond
     // `from` is free yet and something is on its way
-    uint64_t settled(uint64_t from);
+    uint64_t settled(uint64_t from, bool may_wait = true);  // may_wait = false: only what has arrived already
     bool drain();  // waits for every copy
     bool empty() const { return d_q.empty(); }
 
@@ -591,6 +591,7 @@ private:
     enum { R_FREE = 0, R_FILL, R_RUN, R_DONE, R_DRAIN };
     bool grow(round &r, size_t items);
     int fill_direct(int n, gr_vector_const_void_star &input_items);
+    int settle_direct();  // waits for the oldest uploaded piece and consumes what has arrived
     bool cut();                  // the round being filled goes to its worker; another one is filled (if one is free)
     void run(round &r);          // worker thread: everything that waits for the GPU
     bool harvest(bool wait);     // publish finished rounds in order; wait: for every round in flight

@@ -87,6 +87,7 @@ def main():
             fh.write("%d 0.0 30.0 -40.0\n" % p)
     for pin in (True, False):
         for chunk, batch in ((65536, 4096), (1 << 18, 4096), (1 << 20, 8192)):
+            batch = int(os.environ.get("GR80211_CHAIN_BATCH", batch))  # frames per round (experiments)
             run(["chaint", 1, chunk, batch, f_trc, f_iqc], n_chain * L, "chain, 3 threads window %7d batch %5d" % (chunk, batch), pin)
     for f in (f_trc,) + ((f_iqc,) if f_iqc != f_iq else ()):
         os.remove(f)
