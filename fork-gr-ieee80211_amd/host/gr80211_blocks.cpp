@@ -87,6 +87,8 @@ int next_set(const uint8_t *s, int i, int n)
 
 }  // namespace
 
+static void copy_past_cache(void *dst, const void *src, size_t n);  // defined with the output queues below
+
 // ------------------------------------------------------------------------------------ block
 block::block(int n_in, int n_out) : d_read(n_in, 0), d_written(n_out, 0), d_out_tags(n_out), d_tags(n_in) {}
 block::~block() {}
@@ -282,12 +284,121 @@ uploader::uploader(int device) : d_a(device)
     if (const char *e = getenv("GR80211_UPLOAD_STREAMS"))
         if (atoi(e) == 2) d_b.reset(new gpu_session(device));
     if (const char *e = getenv("GR80211_UPLOAD_SPLIT")) d_firstSplit = atoi(e);  // experiments
+    if (const char *e = getenv("GR80211_UPLOAD_STAGE")) d_stageOn = e[0] != '0';  // experiments
+}
+
+uploader::~uploader()
+{
+    if (!d_a.ok()) return;
+    d_a.sync();
+    for (char *p : d_stage)
+        if (p) gr80211_host_free(d_a.ctx(), p);
+}
+
+// Ring bytes [d_pendStart, d_pendStart + d_pendBytes) of every source go on their way to d_pendDst.
+bool uploader::flush_staged()
+{
+    if (!d_pendBytes) return true;
+    long long id = 0;
+    for (int a = 0; a < d_pendSrcs; a++) {
+        id = gr80211_pull_h2d(d_a.ctx(), d_pendDst[a], d_stage[a] + d_pendStart, d_pendBytes, nullptr);
+        if (id < 0) return false;
+    }
+    d_sentRing.push_back({d_pendStart, d_pendStart + d_pendBytes, id});
+    d_nPiece++;
+    d_pendBytes = 0;
+    return true;
+}
+
+bool uploader::stage(int n_src, const char *const *src, char *const *dst, size_t bytes, std::string &err)
+{
+    for (int a = 0; a < n_src; a++)
+        if (!d_stage[a]) {
+            d_stage[a] = static_cast<char *>(gr80211_host_alloc(d_a.ctx(), STAGE_BYTES));
+            if (!d_stage[a]) return false;  // the caller sends the window the other way
+        }
+    // what is waiting goes first unless these bytes follow it, in the ring and in device memory
+    bool follows = d_pendBytes && d_pendSrcs == n_src && d_wpos + bytes <= STAGE_BYTES;
+    for (int a = 0; a < n_src && follows; a++) follows = dst[a] == d_pendDst[a] + d_pendBytes;
+    if (!follows && !flush_staged()) {
+        err = "upload failed: " + d_a.error();
+        return false;
+    }
+    if (d_wpos + bytes > STAGE_BYTES) d_wpos = 0;
+    // room in the ring: pieces sent earlier that overlap [d_wpos, d_wpos + bytes) must have been read
+    while (!d_sentRing.empty()) {
+        const sent &o = d_sentRing.front();
+        const bool overlaps = o.lo < d_wpos + bytes && d_wpos < o.hi;
+        if (!overlaps && gr80211_pull_done(d_a.ctx(), o.id, 0) != 1) break;  // still travelling, but not in the way
+        if (overlaps && gr80211_pull_done(d_a.ctx(), o.id, 1) != 1) {
+            err = "upload failed: " + d_a.error();
+            return false;
+        }
+        d_sentRing.pop_front();
+    }
+    for (const sent &o : d_sentRing)  // (pieces behind a piece that is not in the way)
+        if (o.lo < d_wpos + bytes && d_wpos < o.hi && gr80211_pull_done(d_a.ctx(), o.id, 1) != 1) {
+            err = "upload failed: " + d_a.error();
+            return false;
+        }
+    for (int a = 0; a < n_src; a++) copy_past_cache(d_stage[a] + d_wpos, src[a], bytes);
+    if (!d_pendBytes) {
+        d_pendStart = d_wpos;
+        d_pendSrcs = n_src;
+        for (int a = 0; a < n_src; a++) d_pendDst[a] = dst[a];
+    }
+    d_pendBytes += bytes;
+    d_wpos += bytes;
+    if (d_pendBytes >= STAGE_FLUSH && !flush_staged()) {
+        err = "upload failed: " + d_a.error();
+        return false;
+    }
+    return true;
 }
 
 bool uploader::send(gpu_session &direct, int n_src, const char *const *src, char *const *dst, size_t items, size_t item,
                     uint64_t pos0, bool pinned, std::string &err)
 {
     if (items == 0) return true;
+    size_t src_skip = 0;  // items the staging path has taken already (it ran out of memory part-way)
+    if (d_stageOn && n_src <= 2 && (!pinned || items * item <= STAGE_MAX_PINNED)) {
+        // (a window in ordinary memory of any size, in pieces the ring takes: copying by hand runs beside the pieces
+        // already on their way, where the runtime's copy out of ordinary memory makes the caller wait for all of it)
+        const size_t per = std::max<size_t>(STAGE_FLUSH / item, 1);
+        std::string e2;
+        size_t at = 0;
+        while (at < items) {
+            const size_t cnt = std::min(per, items - at);
+            const char *s2[2];
+            char *d2[2];
+            for (int a = 0; a < n_src; a++) s2[a] = src[a] + at * item, d2[a] = dst[a] + at * item;
+            if (!stage(n_src, s2, d2, cnt * item, e2)) break;
+            at += cnt;
+        }
+        if (at == items) {
+            d_log.add(nullptr, 0, pos0 + items);  // copied out of the window: free at once
+            return true;
+        }
+        if (!e2.empty()) {
+            err = e2;
+            return false;
+        }
+        // no staging memory: what is left goes the other way
+        src_skip = at;
+    }
+    const char *src_rest[2];
+    char *dst_rest[2];
+    if (src_skip) {
+        for (int a = 0; a < n_src; a++) src_rest[a] = src[a] + src_skip * item, dst_rest[a] = dst[a] + src_skip * item;
+        src = src_rest, dst = dst_rest;
+        items -= src_skip;
+        pos0 += src_skip;
+    }
+    // a larger window overtakes nothing that was staged before it
+    if (!flush_staged()) {
+        err = "upload failed: " + d_a.error();
+        return false;
+    }
     if (!pinned) {
         for (int a = 0; a < n_src; a++)
             if (gr80211_copy_h2d(direct.ctx(), dst[a], src[a], items * item, nullptr) != GR80211_OK) {
@@ -340,6 +451,7 @@ bool uploader::send(gpu_session &direct, int n_src, const char *const *src, char
 
 bool uploader::join(gr80211_ctx *c)
 {
+    if (!flush_staged()) return false;
     if (d_nPiece == 0) return true;
     d_nPiece = 0;
     return gr80211_stream_wait(c, nullptr, d_a.ctx(), nullptr) == GR80211_OK &&

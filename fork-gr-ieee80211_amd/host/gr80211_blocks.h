@@ -193,6 +193,9 @@ class uploader
 {
 public:
     explicit uploader(int device);
+    ~uploader();
+    uploader(const uploader &) = delete;
+    uploader &operator=(const uploader &) = delete;
     bool ok() const { return d_a.ok() && (!d_b || d_b->ok()); }
     gpu_session &session() { return d_a; }
     upload_log &log() { return d_log; }
@@ -202,7 +205,7 @@ public:
               uint64_t pos0, bool pinned, std::string &err);
     // what c's stream is given from now on runs after every piece sent so far
     bool join(gr80211_ctx *c);
-    bool sync() { return d_a.sync() && (!d_b || d_b->sync()); }  // every piece sent so far has arrived
+    bool sync() { return flush_staged() && d_a.sync() && (!d_b || d_b->sync()); }  // every piece sent so far has arrived
     void set_first_split(int pieces) { d_firstSplit = pieces; }
 
 private:
@@ -211,6 +214,24 @@ private:
     upload_log d_log;
     unsigned d_nPiece = 0;  // pieces since the last join
     int d_firstSplit = 0;   // pieces a window that finds nothing on its way is cut into (0: by its size)
+    // Small windows (GNU Radio's default buffers hold 64 KB): a copy of their own costs a launch and, for the caller,
+    // the wait until it has read its source.  They are copied by hand into page-locked memory of the uploader instead
+    // -- their items are free at once -- and travel from there in pieces of STAGE_FLUSH bytes, as long as they follow
+    // each other in device memory.
+    // (from page-locked windows up to 96 KB: beyond that the copy that reads the window itself is the cheaper way; from
+    // ordinary memory up to a megabyte, against a copy the caller has to wait for)
+    static constexpr size_t STAGE_MAX_PINNED = (size_t)96 << 10, STAGE_MAX_PAGEABLE = (size_t)1 << 20,
+                            STAGE_FLUSH = (size_t)256 << 10, STAGE_BYTES = (size_t)8 << 20;
+    bool stage(int n_src, const char *const *src, char *const *dst, size_t bytes, std::string &err);
+    bool flush_staged();
+    char *d_stage[2] = {nullptr, nullptr};  // one ring per source
+    size_t d_wpos = 0;                      // where the next bytes go
+    size_t d_pendStart = 0, d_pendBytes = 0;  // copied in, not yet sent
+    char *d_pendDst[2] = {nullptr, nullptr};
+    int d_pendSrcs = 0;
+    struct sent { size_t lo, hi; long long id; };  // ring bytes [lo, hi) are free once pull `id` has run
+    std::deque<sent> d_sentRing;
+    bool d_stageOn = true;
 };
 
 // Items waiting for the GPU, kept in device memory: every window of the stream is uploaded when it arrives, so the
