@@ -285,6 +285,7 @@ uploader::uploader(int device) : d_a(device)
         if (atoi(e) == 2) d_b.reset(new gpu_session(device));
     if (const char *e = getenv("GR80211_UPLOAD_SPLIT")) d_firstSplit = atoi(e);  // experiments
     if (const char *e = getenv("GR80211_UPLOAD_STAGE")) d_stageOn = e[0] != '0';  // experiments
+    if (const char *e = getenv("GR80211_STAGE_MAX_PINNED")) d_stageMaxPinned = (size_t)atoll(e);
 }
 
 uploader::~uploader()
@@ -361,7 +362,7 @@ bool uploader::send(gpu_session &direct, int n_src, const char *const *src, char
 {
     if (items == 0) return true;
     size_t src_skip = 0;  // items the staging path has taken already (it ran out of memory part-way)
-    if (d_stageOn && n_src <= 2 && (!pinned || items * item <= STAGE_MAX_PINNED)) {
+    if (d_stageOn && n_src <= 2 && (!pinned || items * item <= d_stageMaxPinned)) {
         // (a window in ordinary memory of any size, in pieces the ring takes: copying by hand runs beside the pieces
         // already on their way, where the runtime's copy out of ordinary memory makes the caller wait for all of it)
         const size_t per = std::max<size_t>(STAGE_FLUSH / item, 1);
@@ -864,6 +865,8 @@ decode::decode(bool ifdebug, int batch_frames, int device)
         d_err = "gr80211_create failed";
         return;
     }
+    // soft bits: windows of 64 k items (256 KB) still do better copied by hand (1.10 -> 1.21 Gsamples/s-equivalent)
+    d_up.set_stage_max_pinned((size_t)300 << 10);
     for (round &r : d_round) {
         r.gpu.reset(new gpu_session(device));
         if (!r.gpu->ok()) {
@@ -1827,6 +1830,9 @@ demod::demod(int n_rx, int mupos, int batch_frames, int device)
       d_device(device), d_out(sizeof(float)), d_up(new uploader(device))
 {
     if (!d_up->ok()) d_err = "gr80211_create failed";
+    // this block's thread also hands soft bits on: windows of 64 k items (512 KB) copied by hand leave it free sooner
+    // than pieces it has to see arrive (three-block chain 342 -> 385 Msamples/s)
+    d_up->set_stage_max_pinned((size_t)600 << 10);
     for (int i = 0; i < N_ROUNDS; i++) {
         d_round.emplace_back(new round());
         d_round.back()->gpu.reset(new gpu_session(device));

@@ -21,6 +21,7 @@
 
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <complex>
 #include <cstdint>
 #include <deque>
@@ -207,6 +208,8 @@ public:
     bool join(gr80211_ctx *c);
     bool sync() { return flush_staged() && d_a.sync() && (!d_b || d_b->sync()); }  // every piece sent so far has arrived
     void set_first_split(int pieces) { d_firstSplit = pieces; }
+    // page-locked windows of up to `bytes` are copied by hand too (see below); the environment's limit, if set, stays
+    void set_stage_max_pinned(size_t bytes) { if (!getenv("GR80211_STAGE_MAX_PINNED")) d_stageMaxPinned = bytes; }
 
 private:
     gpu_session d_a;
@@ -232,6 +235,7 @@ private:
     struct sent { size_t lo, hi; long long id; };  // ring bytes [lo, hi) are free once pull `id` has run
     std::deque<sent> d_sentRing;
     bool d_stageOn = true;
+    size_t d_stageMaxPinned = STAGE_MAX_PINNED;  // GR80211_STAGE_MAX_PINNED=<bytes>: another limit (experiments)
 };
 
 // Items waiting for the GPU, kept in device memory: every window of the stream is uploaded when it arrives, so the
