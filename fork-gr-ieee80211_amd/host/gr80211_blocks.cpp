@@ -286,6 +286,7 @@ uploader::uploader(int device) : d_a(device)
     if (const char *e = getenv("GR80211_UPLOAD_SPLIT")) d_firstSplit = atoi(e);  // experiments
     if (const char *e = getenv("GR80211_UPLOAD_STAGE")) d_stageOn = e[0] != '0';  // experiments
     if (const char *e = getenv("GR80211_STAGE_MAX_PINNED")) d_stageMaxPinned = (size_t)atoll(e);
+    if (const char *e = getenv("GR80211_STAGE_BYTES")) d_stageBytes = std::max<size_t>((size_t)atoll(e), 4096);
 }
 
 uploader::~uploader()
@@ -313,19 +314,20 @@ bool uploader::flush_staged()
 
 bool uploader::stage(int n_src, const char *const *src, char *const *dst, size_t bytes, std::string &err)
 {
+    if (bytes > d_stageBytes) return false;  // (only with a ring made small on purpose)
     for (int a = 0; a < n_src; a++)
         if (!d_stage[a]) {
-            d_stage[a] = static_cast<char *>(gr80211_host_alloc(d_a.ctx(), STAGE_BYTES));
+            d_stage[a] = static_cast<char *>(gr80211_host_alloc(d_a.ctx(), d_stageBytes));
             if (!d_stage[a]) return false;  // the caller sends the window the other way
         }
     // what is waiting goes first unless these bytes follow it, in the ring and in device memory
-    bool follows = d_pendBytes && d_pendSrcs == n_src && d_wpos + bytes <= STAGE_BYTES;
+    bool follows = d_pendBytes && d_pendSrcs == n_src && d_wpos + bytes <= d_stageBytes;
     for (int a = 0; a < n_src && follows; a++) follows = dst[a] == d_pendDst[a] + d_pendBytes;
     if (!follows && !flush_staged()) {
         err = "upload failed: " + d_a.error();
         return false;
     }
-    if (d_wpos + bytes > STAGE_BYTES) d_wpos = 0;
+    if (d_wpos + bytes > d_stageBytes) d_wpos = 0;
     // room in the ring: pieces sent earlier that overlap [d_wpos, d_wpos + bytes) must have been read
     while (!d_sentRing.empty()) {
         const sent &o = d_sentRing.front();

@@ -236,6 +236,7 @@ private:
     std::deque<sent> d_sentRing;
     bool d_stageOn = true;
     size_t d_stageMaxPinned = STAGE_MAX_PINNED;  // GR80211_STAGE_MAX_PINNED=<bytes>: another limit (experiments)
+    size_t d_stageBytes = STAGE_BYTES;           // GR80211_STAGE_BYTES=<bytes>: another ring size (tests: a ring that wraps at once)
 };
 
 // Items waiting for the GPU, kept in device memory: every window of the stream is uploaded when it arrives, so the

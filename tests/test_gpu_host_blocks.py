@@ -93,13 +93,17 @@ def test_rx_block_siso_stream(tmp_path, oracle, chunk, batch):
     assert mpdus == [f["mpdu"] for f in frames]
 
 
-@pytest.mark.parametrize("env", [{"GR80211_UPLOAD": "dma"}, {"GR80211_UPLOAD": "pull"},
-                                 {"GR80211_UPLOAD_STREAMS": "2", "GR80211_UPLOAD_SPLIT": "3"}, {"GR80211_PUMP_PIN": "0"},
+@pytest.mark.parametrize("env", [{"GR80211_UPLOAD": "dma", "GR80211_UPLOAD_STAGE": "0"},
+                                 {"GR80211_UPLOAD": "pull", "GR80211_UPLOAD_STAGE": "0"},
+                                 {"GR80211_UPLOAD_STREAMS": "2", "GR80211_UPLOAD_SPLIT": "3", "GR80211_UPLOAD_STAGE": "0"},
+                                 {"GR80211_PUMP_PIN": "0", "GR80211_UPLOAD_STAGE": "0"}, {"GR80211_PUMP_PIN": "0"}, {},
+                                 {"GR80211_STAGE_MAX_PINNED": "1000"}, {"GR80211_STAGE_BYTES": "40000"},
                                  {"GR80211_RX_MAX_HOLD": "20000", "GR80211_DECODE_MAX_HOLD": "5000"}])
 def test_rx_and_decode_blocks_whatever_way_the_windows_travel(tmp_path, pkg, rxctx, oracle, env):
     """The streaming blocks give the same messages whether their windows go up by the runtime's copy engines, by the
-    copy kernel, by two upload streams in three pieces, synchronously from ordinary memory, or in rounds cut by the
-    sample limit instead of the frame count."""
+    copy kernel, by two upload streams in three pieces, synchronously from ordinary memory, copied by hand into the
+    uploader's page-locked ring (the default for windows this small, from page-locked and from ordinary memory), partly
+    one way and partly the other, through a ring so small that it wraps with every window, or in rounds cut by the sample limit instead of the frame count."""
     iq0, triggers, frames = siso_stream(0.002, 6)
     want, n_frames = model_chain(oracle, iq0, None, triggers)
     tf, files = write_stream(tmp_path, iq0, None, triggers)
