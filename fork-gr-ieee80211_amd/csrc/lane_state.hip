@@ -40,6 +40,7 @@ namespace {
 
 constexpr int LS_BLOCK = 60;   // steps per survivor block: a multiple of 6 (phases) and of every puncture period
 constexpr int LS_WAVES = 4;    // frames per workgroup, one per wave (the four SIMDs of a CU); the waves share nothing
+constexpr int LS_WARM_AHEAD = 1024;  // soft bits between the scalar loads and the lines being brought into L2
 constexpr int TB_WARM = 96;    // steps a lane walks above its segment before its bits count
 constexpr int TB_UNIT = 96;    // segment lengths are multiples of lcm(6 phases, 32 bits per word)
 
@@ -51,6 +52,16 @@ template <> struct LsRate<CR_23> { static constexpr int SUB = 12; };
 template <> struct LsRate<CR_34> { static constexpr int SUB = 12; };
 template <> struct LsRate<CR_56> { static constexpr int SUB = 10; };
 
+__device__ __forceinline__ int ls_clamp(int c, int n) { c = c < n ? c : n - 1; return c < 0 ? 0 : c; }
+// A load whose only purpose is to bring its cache line into L2.  As inline assembly it stays where it is written (the
+// compiler moves an ordinary load down to its first use); its register is held until ls_touched has waited for it.
+__device__ __forceinline__ float ls_touch(const float *p)
+{
+    float v;
+    asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+__device__ __forceinline__ void ls_touched(float v) { asm volatile("s_waitcnt vmcnt(0)" ::"v"(v) : "memory"); }
 __device__ __forceinline__ int ror6(int v, int k) { return ((v >> k) | (v << (6 - k))) & 63; }
 
 // Per-lane constants of the six phases: coefficient of the first and second soft bit in the branch metric along
@@ -220,6 +231,12 @@ __device__ __forceinline__ void ls_forward(cfloatp base, int n, int T, unsigned 
     ls_load<NC, false>(cur, base, 0, n);
     uint32_t plo = 0, phi = 0;
     const int nblk = (T + LS_BLOCK - 1) / LS_BLOCK;
+    // The soft bits were written by another kernel, in general on another XCD, so they are in memory and not in this
+    // XCD's L2; a scalar load that has to go there returns after more steps than one sub-body lasts.  A vector load
+    // per block, whose value nobody needs, touches the cache lines LS_WARM_AHEAD soft bits ahead of the scalar loads
+    // (a block reads at most 120 soft bits, the eight lanes' addresses span 128), so that these find them in L2.
+    const float *gl = (const float *)(unsigned long long)base;
+    const float warm0 = ls_touch(gl + ls_clamp(lane * 16, n));
     // a block reads its own soft bits and, ahead of time, the first sub-body of the next block: blocks for which all
     // of that lies inside the frame run without index clamping
     constexpr int BLOCK_COLS = LS_BLOCK / Rate<CR>::P * Rate<CR>::COLS;
@@ -228,16 +245,21 @@ __device__ __forceinline__ void ls_forward(cfloatp base, int n, int T, unsigned 
     int b = 0;
 #pragma unroll 1
     for (; b < ninside; b++) {
+        const float warm = ls_touch(gl + ls_clamp(col + LS_WARM_AHEAD + (lane & 7) * 16, n));
         ls_block<CR, true>(m, cur, base, col, n, k, plo, phi, std::make_integer_sequence<int, LS_BLOCK / SUB>{});
+        ls_touched(warm);
         const int t = b * LS_BLOCK + lane;
         if (lane < LS_BLOCK && t < T) w64[t] = ((unsigned long long)phi << 32) | plo;
     }
 #pragma unroll 1
     for (; b < nblk; b++) {
+        const float warm = ls_touch(gl + ls_clamp(col + LS_WARM_AHEAD + (lane & 7) * 16, n));
         ls_block<CR, false>(m, cur, base, col, n, k, plo, phi, std::make_integer_sequence<int, LS_BLOCK / SUB>{});
+        ls_touched(warm);
         const int t = b * LS_BLOCK + lane;
         if (lane < LS_BLOCK && t < T) w64[t] = ((unsigned long long)phi << 32) | plo;
     }
+    ls_touched(warm0);
 }
 
 // One pass of the walk back.  Lane k walks warm + seg steps down from time (k + 1) * seg + warm, starting in lane
