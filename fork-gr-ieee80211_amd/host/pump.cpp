@@ -492,7 +492,8 @@ static int run(int argc, char **argv)
             l->w.store(n);
             l->closed.store(true);
         }
-        const size_t W = 32;
+        // windows a ring between two blocks holds (a scheduler's buffer size in windows)
+        const size_t W = getenv("GR80211_PUMP_RING_WINDOWS") ? (size_t)std::max(2, atoi(getenv("GR80211_PUMP_RING_WINDOWS"))) : 32;
         ring_link l_s0(8, W, (size_t)chunk, pinned ? dm.get() : nullptr), l_s1(8, W, (size_t)chunk, pinned ? dm.get() : nullptr),
             l_llr(4, W, (size_t)chunk, pinned ? dc.get() : nullptr);
         std::vector<ring_link *> in_sg = {&l_sync, &l_a}, out_sg = {&l_s0}, in_dm = {&l_s0};
