@@ -861,8 +861,9 @@ decode::sptr decode::make(bool ifdebug, int batch_frames, int device)
 }
 
 decode::decode(bool ifdebug, int batch_frames, int device)
-    : block(1), d_debug(ifdebug), d_batch(batch_frames < 1 ? 1 : batch_frames), d_up(device)
+    : block(1), d_debug(ifdebug), d_batch(batch_frames < 1 ? 4096 : batch_frames), d_up(device)
 {
+    d_finish = batch_frames < 1;  // made like the reference's block: timed like it
     if (!d_up.ok()) {
         d_err = "gr80211_create failed";
         return;
@@ -1035,6 +1036,12 @@ int decode::general_work(int, gr_vector_int &ninput_items, gr_vector_const_void_
                 d_nPdu++;
             } else {
                 d_state = S_COLLECT;
+                if (d_finish && !d_fill->desc.empty() && t_nTotal > (long)(n - used)) {
+                    // this packet ends in a later call: the ones before it do not wait for it
+                    if (!send(in, span, used)) return 0;
+                    span = used;
+                    if (!cut()) return 0;
+                }
                 round &f = *d_fill;
                 if (f.desc.empty()) {
                     // the round's first packet: the round holds the stream from here on
@@ -1083,6 +1090,11 @@ int decode::general_work(int, gr_vector_int &ninput_items, gr_vector_const_void_
     }
     if (!send(in, span, n)) return 0;
     log.set_enqueued(r0 + (uint64_t)n);
+    if (d_finish) {
+        // what this call completed is decoded and published before it returns
+        if (d_state != S_COLLECT && !d_fill->desc.empty() && !cut()) return 0;
+        if (!d_flight.empty() && !advance(true, true)) return 0;
+    }
     consume_each((int)(log.settled(r0) - r0));
     return 0;
 }
@@ -1828,9 +1840,10 @@ demod::sptr demod::make(int n_rx, int mupos, int, int batch_frames, int device)
 }
 
 demod::demod(int n_rx, int mupos, int batch_frames, int device)
-    : block(n_rx == 2 ? 2 : 1, 1), d_nrx(n_rx == 2 ? 2 : 1), d_muPos(mupos ? 1 : 0), d_batch(batch_frames < 1 ? 1 : batch_frames),
+    : block(n_rx == 2 ? 2 : 1, 1), d_nrx(n_rx == 2 ? 2 : 1), d_muPos(mupos ? 1 : 0), d_batch(batch_frames < 1 ? 4096 : batch_frames),
       d_device(device), d_out(sizeof(float)), d_up(new uploader(device))
 {
+    d_finish = batch_frames < 1;  // made like the reference's block: timed like it
     if (!d_up->ok()) d_err = "gr80211_create failed";
     // this block's thread also hands soft bits on: windows of 64 k items (512 KB) copied by hand leave it free sooner
     // than pieces it has to see arrive (three-block chain 342 -> 385 Msamples/s)
@@ -1918,7 +1931,8 @@ int demod::general_work(int noutput_items, gr_vector_int &ninput_items, gr_vecto
         bool pinned = d_up->ok();
         for (int a = 0; a < d_nrx; a++) pinned = pinned && is_pinned(input_items[(size_t)a], (size_t)n * sizeof(gr_complex));
         if (const char *e = getenv("GR80211_DEMOD_DIRECT")) pinned = pinned && e[0] != '0';  // experiments
-        d_mode = pinned ? M_DIRECT : M_STAGED;
+        // (a round that is to be finished within the call collects its frames by hand: it is a frame or two)
+        d_mode = pinned && !d_finish ? M_DIRECT : M_STAGED;
     }
     if (d_out.pending() > OUT_QUEUE_LIMIT) n = 0;  // input is only taken while the soft bits produced find room
     int used = 0;
@@ -1967,11 +1981,20 @@ int demod::general_work(int noutput_items, gr_vector_int &ninput_items, gr_vecto
             d.snr = (float)tag_value(tags, "snr", 0.0);
             d.rssi = (float)tag_value(tags, "rssi", 0.0);
             d.mu_pos = (uint32_t)d_muPos;
-            d_nSeen++;
             const tag_t *ch = tag_find(tags, "chan");
-            if (d.nsamp < 0 || d.nsamp > (1 << 24) || !ch || ch->cvec.size() < 64) {
+            const bool usable = !(d.nsamp < 0 || d.nsamp > (1 << 24) || !ch || ch->cvec.size() < 64);
+            if (!(usable && d_finish && !r.desc.empty() && d.nsamp > n - used)) d_nSeen++;  // (else looked at again below)
+            if (!usable) {
                 // nothing a frame can be taken from: pass over this item and look for the next tagged one
                 used++;
+                continue;
+            }
+            if (d_finish && !r.desc.empty() && d.nsamp > n - used) {
+                // this frame ends in a later call: the ones before it do not wait for it (the item is looked at again)
+                if (!cut()) {
+                    consume_each(used);
+                    return 0;
+                }
                 continue;
             }
             r.desc.push_back(d);
@@ -2010,6 +2033,12 @@ int demod::general_work(int noutput_items, gr_vector_int &ninput_items, gr_vecto
         }
     }
     if (d_mode != M_DIRECT) consume_each(used);
+    if (d_finish && d_mode != M_DIRECT) {
+        // what this call completed is demodulated before it returns (the 320 items passed over after a frame carry
+        // nothing: the frame is complete with its last sample)
+        if (d_fill && d_state != S_COLLECT && !d_fill->desc.empty() && !cut()) return 0;
+        if (!d_flight.empty() && !harvest(true)) return 0;
+    }
     n = ninput_items[0];
     if (output_items.empty()) return 0;
     tags.clear();
@@ -2238,7 +2267,9 @@ bool demod::cut()
     r.state.store(R_RUN);
     d_flight.push_back(&r);
     if (r.worker.joinable()) r.worker.join();
-    r.worker = std::thread([this, &r] { run(r); });
+    // a round the call is going to wait for anyway runs on the caller's thread: starting one costs as much as the round
+    if (d_finish) run(r);
+    else r.worker = std::thread([this, &r] { run(r); });
     return true;
 }
 

@@ -368,7 +368,7 @@ public:
     typedef std::shared_ptr<decode> sptr;
     // ifdebug as in ieee80211::decode::make(bool) (the reference only prints with it); batch_frames and
     // device are the GPU side's knobs and default to values that keep a stream decoder busy.
-    static sptr make(bool ifdebug = false, int batch_frames = 4096, int device = 0);
+    static sptr make(bool ifdebug = false, int batch_frames = 0, int device = 0);
     ~decode() override;
 
     void forecast(int noutput_items, gr_vector_int &ninput_items_required) override;
@@ -380,6 +380,12 @@ public:
     // the reference's ifdebug after construction, and where its lines go (stdout by default)
     void set_debug(bool on) { d_debug = on; }
     void set_debug_output(FILE *f) { d_debugOut = f; }
+    // The reference publishes a packet in the call that brings its last soft bit (lib/decode_impl.cc:128-160).  With
+    // this on, the block does too: the packets a call completes form a round of their own, whatever batch_frames says,
+    // and the call waits for it.  For live reception, where the next call may be a long time coming; a stream played
+    // at full speed does better without.  On by itself when the block was made without a batch size.
+    void set_finish_in_call(bool on) { d_finish = on; }
+    bool finish_in_call() const { return d_finish; }
     uint64_t packets_correct() const { return d_nPktCorrect; }
     // soft bits a round holds at most before it is cut (at the next packet boundary) whatever the packet count
     void set_max_hold(size_t items) { d_maxHold = items < 4096 ? 4096 : items; }
@@ -425,6 +431,7 @@ private:
     std::deque<round *> d_flight;
     size_t d_maxHold = (size_t)1 << 25;
     bool d_strict = false;
+    bool d_finish = false;
     enum { S_IDLE, S_COLLECT, S_CLEAN } d_state = S_IDLE;
     // tags of the packet being collected (lib/decode_impl.cc:77-88)
     long t_format = 0, t_len = 0, t_nTotal = 0, t_cr = 0, t_mcs = 0, t_ampdu = 0, v_trellis = 0;
@@ -572,7 +579,7 @@ class demod : public block
 {
 public:
     typedef std::shared_ptr<demod> sptr;
-    static sptr make(int n_rx = 1, int mupos = 0, int mugid = 2, int batch_frames = 4096, int device = 0);
+    static sptr make(int n_rx = 1, int mupos = 0, int mugid = 2, int batch_frames = 0, int device = 0);
     ~demod() override;
     void forecast(int noutput_items, gr_vector_int &ninput_items_required) override;
     int general_work(int noutput_items, gr_vector_int &ninput_items, gr_vector_const_void_star &input_items,
@@ -582,6 +589,12 @@ public:
     uint64_t frames_seen() const { return d_nSeen; }
     uint64_t rounds_cut() const { return d_nRounds; }
     void set_mu_pos(int pos) { d_muPos = pos ? 1 : 0; }
+    // The reference hands on a frame's soft bits symbol by symbol as its samples arrive (lib/demod_impl.cc:279-314).
+    // With this on, the frames a call completes form a round of their own and the call waits for it, so their soft
+    // bits leave in that call (as far as the output buffer has room).  For live reception; see decode.  Set before the
+    // first window.  On by itself when the block was made without a batch size.
+    void set_finish_in_call(bool on) { d_finish = on; }
+    bool finish_in_call() const { return d_finish; }
 
 protected:
     gr80211_ctx *pin_context() override { return !d_round.empty() && d_round[0]->gpu ? d_round[0]->gpu->ctx() : nullptr; }
@@ -624,6 +637,7 @@ private:
     bool harvest_front();        // the same after waiting for the oldest round still running
     round *free_round();
     int d_nrx, d_muPos, d_batch, d_device;
+    bool d_finish = false;
     // Three rounds to begin with (one filling, two on their way); more are made when the soft bits of finished rounds
     // leave slowly (small output buffers), up to MAX_ROUNDS, so that input is only refused for lack of output room.
     static constexpr int N_ROUNDS = 3, MAX_ROUNDS = 16;

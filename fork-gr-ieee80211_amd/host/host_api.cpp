@@ -41,15 +41,16 @@ gr80211_block *gr80211_block_create(int kind, int batch_frames, int device)
     h->kind = kind;
     const int batch = batch_frames > 0 ? batch_frames : 4096;
     switch (kind) {
-    case GR80211_BLOCK_DECODE: h->b = decode::make(false, batch, device); h->n_in = 1; break;
+    // decode and demod made without a batch size finish a packet in the call that completes it, as the reference does
+    case GR80211_BLOCK_DECODE: h->b = decode::make(false, batch_frames > 0 ? batch_frames : 0, device); h->n_in = 1; break;
     case GR80211_BLOCK_RX: h->b = rx::make(1, batch, device); h->n_in = 2; break;
     case GR80211_BLOCK_RX2: h->b = rx::make(2, batch, device); h->n_in = 3; break;
     case GR80211_BLOCK_CAPTURE: h->b = capture_rx::make(1, device); h->n_in = 1; break;
     case GR80211_BLOCK_CAPTURE2: h->b = capture_rx::make(2, device); h->n_in = 2; break;
     case GR80211_BLOCK_SIGNAL: h->b = signal::make(1, batch, device); h->n_in = 2; h->n_out = 1; break;
     case GR80211_BLOCK_SIGNAL2: h->b = signal::make(2, batch, device); h->n_in = 3; h->n_out = 2; break;
-    case GR80211_BLOCK_DEMOD: h->b = demod::make(1, 0, 2, batch, device); h->n_in = 1; h->n_out = 1; break;
-    case GR80211_BLOCK_DEMOD2: h->b = demod::make(2, 0, 2, batch, device); h->n_in = 2; h->n_out = 1; break;
+    case GR80211_BLOCK_DEMOD: h->b = demod::make(1, 0, 2, batch_frames > 0 ? batch_frames : 0, device); h->n_in = 1; h->n_out = 1; break;
+    case GR80211_BLOCK_DEMOD2: h->b = demod::make(2, 0, 2, batch_frames > 0 ? batch_frames : 0, device); h->n_in = 2; h->n_out = 1; break;
     default: g_create_err = "gr80211_block_create: unknown block kind"; return nullptr;
     }
     if (!h->b || !h->b->last_error().empty()) {
@@ -139,6 +140,12 @@ int gr80211_block_set_option(gr80211_block *b, int option, int value)
     if (option == GR80211_OPT_DEBUG) {
         if (!d) return -1;
         d->set_debug(value != 0);
+        return 0;
+    }
+    if (option == GR80211_OPT_FINISH_IN_CALL) {
+        if (!d && !dm) return -1;
+        if (d) d->set_finish_in_call(value != 0);
+        if (dm) dm->set_finish_in_call(value != 0);
         return 0;
     }
     if (option == GR80211_OPT_AMPDU_STRICT) {

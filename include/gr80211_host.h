@@ -76,10 +76,21 @@ typedef struct {
                                       running per-MCS counts of packets whose FCS held, in the reference's wording
                                       (lib/decode_impl.cc:375-411,453-509: "ieee80211 decode, vht crc32 correct, total:...") */
 
+#define GR80211_OPT_FINISH_IN_CALL 3 /* DECODE, DEMOD(2): 1 = what a call completes leaves in that call -- the packets (frames) whose last
+                                      item the window brings form a round of their own, whatever batch_frames says, and the call
+                                      waits for it; the reference's timing (lib/decode_impl.cc:128-160 publishes within the call,
+                                      lib/demod_impl.cc:279-314 hands soft bits on symbol by symbol).  For live reception, where
+                                      the next call may be long in coming; 0 = rounds of batch_frames, nothing waited for, for
+                                      streams played at full speed.  Default: 1 for blocks created with batch_frames <= 0, else 0.
+                                      DEMOD: set before the first window.  The other kinds take continuous input and publish
+                                      within a window or two whatever this says. */
+
 typedef struct gr80211_block gr80211_block;
 typedef void (*gr80211_msg_fn)(void *user, const uint8_t *blob, int len);
 
-/* batch_frames: frames (packets) collected before the GPU is called; <= 0 selects the default. */
+/* batch_frames: frames (packets) collected before the GPU is called; <= 0 selects the default: 4096, and for DECODE and
+   DEMOD(2) the timing of the reference's blocks on top (GR80211_OPT_FINISH_IN_CALL = 1), so that a block made the way
+   the reference makes its own never sits on a packet while the stream is silent. */
 gr80211_block *gr80211_block_create(int kind, int batch_frames, int device);
 void gr80211_block_destroy(gr80211_block *b);
 void gr80211_block_set_msg_handler(gr80211_block *b, gr80211_msg_fn fn, void *user);

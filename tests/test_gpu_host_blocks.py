@@ -477,6 +477,71 @@ def test_streaming_abi_signal_demod_decode_chain(pkg, oracle, two, chunk, nout, 
     assert got == want
 
 
+@pytest.mark.parametrize("whole_frames", [True, False])
+def test_blocks_made_without_a_batch_size_finish_within_the_call(pkg, oracle, whole_frames):
+    """demod and decode made the way the reference makes its own (no batch size) keep its timing: a frame's soft bits
+    leave demod, and a packet's messages leave decode, in the call that brings the last item (lib/demod_impl.cc:279-314,
+    lib/decode_impl.cc:128-160), so that nothing waits for a later call while the stream is silent.  Nothing is flushed
+    here: what the calls themselves returned is all there is."""
+    from importlib import import_module
+    stream = import_module("fork-gr-ieee80211_amd.stream")
+    iq0, triggers, frames = siso_stream(0.002, 6)
+    want, n_frames = model_chain(oracle, iq0, None, triggers)
+    sync, tags = sync_stream(len(iq0), triggers)
+    with stream.StreamBlock(stream.SIGNAL, 8) as sg:
+        sg.run([sync, iq0], tags, 4096, 8192)
+        items, sig_tags = sg.output(0), [(t[0], 0, t[1], t[2], t[3]) for t in sg.out_tags]
+    nsamp = [int(t[3]) for t in sig_tags if t[2] == "nsamp"]
+    assert len(nsamp) == n_frames
+
+    def play(b, data, tg, bounds, nout):
+        """Windows end at `bounds`; after every call: (items consumed so far, what the block has given so far)."""
+        at, seen = 0, []
+        for end in bounds:
+            while at < end:
+                got = b.work([data[at:end]], [t for t in tg if at <= t[0] < end], nout)
+                assert got > 0, "a window of new items was not taken"
+                at += got
+            seen.append((at, sum(len(x) for x in b.out[0]) if b.n_out else len(b.msgs)))
+        return seen
+
+    if whole_frames:
+        ends = list(np.cumsum(np.array(nsamp) + 320) - 320)       # a window ends with a frame's last sample ...
+        ends[-1] = len(items)
+    else:
+        ends = list(range(1500, len(items), 1500)) + [len(items)]   # ... or anywhere
+    with stream.StreamBlock(stream.DEMOD) as dm:                    # batch size 0: the default
+        seen = play(dm, items, sig_tags, ends, 1 << 20)
+        llr, llr_tags = dm.output(0), [(t[0], 0, t[1], t[2], t[3]) for t in dm.out_tags if t[1] in stream.TAG_KEYS[:11]]
+        totals = [int(t[3]) for t in llr_tags if t[2] == "total"]
+        assert len(totals) == n_frames and len(llr) == sum(totals)
+        if whole_frames:
+            assert [g for _, g in seen] == list(np.cumsum(totals)), "soft bits of a complete frame waited for a later call"
+    firsts = [t[0] for t in llr_tags if t[2] == "total"]
+    if whole_frames:
+        ends = [f + t for f, t in zip(firsts, totals)]
+    else:
+        ends = list(range(5000, len(llr), 5000)) + [len(llr)]
+    with stream.StreamBlock(stream.DECODE) as dc:
+        seen = play(dc, llr, llr_tags, ends, 0)
+        assert dc.msgs == want, "messages of complete packets waited for a later call"
+        counts = [g for _, g in seen]
+        assert counts == sorted(counts) and counts[-1] == len(want)
+        if whole_frames:
+            assert counts[0] >= 1 and all(b > a for a, b in zip(counts, counts[1:])) or len(want) < n_frames
+    # the option turns the timing off and on whatever the batch size
+    with stream.StreamBlock(stream.DECODE, 1000) as dc:
+        dc.set_option(stream.OPT_FINISH_IN_CALL, 1)
+        play(dc, llr, llr_tags, [len(llr)], 0)
+        assert dc.msgs == want
+    with stream.StreamBlock(stream.DECODE) as dc:
+        dc.set_option(stream.OPT_FINISH_IN_CALL, 0)
+        play(dc, llr, llr_tags, [len(llr)], 0)
+        assert dc.msgs == []          # a round of 4096 packets is not full: they wait for it, or for the end of the stream
+        dc.flush()
+        assert dc.msgs == want
+
+
 # GR80211_STREAM_SEEDS=N: a longer sweep over seeds 1..N
 @pytest.mark.parametrize("seed", list(range(1, 1 + int(os.environ.get("GR80211_STREAM_SEEDS", "6")))))
 def test_streaming_chain_with_windows_that_change_every_call(pkg, oracle, seed):
