@@ -39,7 +39,8 @@ gr80211_block *gr80211_block_create(int kind, int batch_frames, int device)
 {
     std::unique_ptr<gr80211_block> h(new gr80211_block());
     h->kind = kind;
-    const int batch = batch_frames > 0 ? batch_frames : 4096;
+    // no batch size: rounds of one frame, so that a frame never waits for others on a quiet channel
+    const int batch = batch_frames > 0 ? batch_frames : 1;
     switch (kind) {
     // decode and demod made without a batch size finish a packet in the call that completes it, as the reference does
     case GR80211_BLOCK_DECODE: h->b = decode::make(false, batch_frames > 0 ? batch_frames : 0, device); h->n_in = 1; break;
@@ -146,6 +147,14 @@ int gr80211_block_set_option(gr80211_block *b, int option, int value)
         if (!d && !dm) return -1;
         if (d) d->set_finish_in_call(value != 0);
         if (dm) dm->set_finish_in_call(value != 0);
+        return 0;
+    }
+    if (option == GR80211_OPT_MAX_HOLD) {
+        if (value < 1 || dm) return -1;
+        if (d) d->set_max_hold((size_t)value);
+        else if (c) c->set_max_hold((size_t)value);
+        else if (r) r->set_max_hold((size_t)value);
+        else return -1;
         return 0;
     }
     if (option == GR80211_OPT_AMPDU_STRICT) {

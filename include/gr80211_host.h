@@ -84,13 +84,20 @@ typedef struct {
                                       streams played at full speed.  Default: 1 for blocks created with batch_frames <= 0, else 0.
                                       DEMOD: set before the first window.  The other kinds take continuous input and publish
                                       within a window or two whatever this says. */
+#define GR80211_OPT_MAX_HOLD 4       /* items a round holds at most before it is cut whatever the number of frames in it: soft bits for
+                                      DECODE (at least 4096), samples from the first pending sync byte on for RX, SIGNAL and CAPTURE
+                                      (at least four times the longest frame, 438 016 samples; CAPTURE cuts its rounds by this
+                                      alone).  Bounds the time a frame waits for its round on a channel with little traffic. */
 
 typedef struct gr80211_block gr80211_block;
 typedef void (*gr80211_msg_fn)(void *user, const uint8_t *blob, int len);
 
-/* batch_frames: frames (packets) collected before the GPU is called; <= 0 selects the default: 4096, and for DECODE and
-   DEMOD(2) the timing of the reference's blocks on top (GR80211_OPT_FINISH_IN_CALL = 1), so that a block made the way
-   the reference makes its own never sits on a packet while the stream is silent. */
+/* batch_frames: frames (packets) a round collects before it goes to the GPU -- the knob between latency and rate.
+   <= 0, the default, is for live reception: a block made the way the reference makes its own never sits on a frame while
+   the channel is quiet.  RX and SIGNAL then work in rounds of one frame (a message leaves two windows after the
+   frame's last sample), DECODE and DEMOD(2) keep the reference's timing (GR80211_OPT_FINISH_IN_CALL = 1).  A stream
+   played at full speed wants thousands (the rates quoted for these blocks are at 4096 and 16 384).  CAPTURE(2) cuts
+   its rounds by samples (GR80211_OPT_MAX_HOLD) and ignores this. */
 gr80211_block *gr80211_block_create(int kind, int batch_frames, int device);
 void gr80211_block_destroy(gr80211_block *b);
 void gr80211_block_set_msg_handler(gr80211_block *b, gr80211_msg_fn fn, void *user);

@@ -529,6 +529,21 @@ def test_blocks_made_without_a_batch_size_finish_within_the_call(pkg, oracle, wh
         assert counts == sorted(counts) and counts[-1] == len(want)
         if whole_frames:
             assert counts[0] >= 1 and all(b > a for a, b in zip(counts, counts[1:])) or len(want) < n_frames
+    # the fused block reads the antenna stream, which never pauses: made without a batch size it works in rounds of one
+    # frame and publishes on the calls that follow, none of which needs to bring a frame
+    import time
+    with stream.StreamBlock(stream.RX) as rx:
+        at = 0
+        while at < len(iq0):
+            got = rx.work([sync[at:at + 4096], iq0[at:at + 4096]], [t for t in tags if at <= t[0] < at + 4096])
+            assert got > 0
+            at += got
+        for _ in range(400):
+            if len(rx.msgs) >= len(want):
+                break
+            time.sleep(0.005)
+            rx.work([sync[:0], iq0[:0]], [])
+        assert rx.msgs == want
     # the option turns the timing off and on whatever the batch size
     with stream.StreamBlock(stream.DECODE, 1000) as dc:
         dc.set_option(stream.OPT_FINISH_IN_CALL, 1)

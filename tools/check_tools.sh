@@ -23,6 +23,7 @@ run 200 python3 tools/chain_rate.py 4000
 run 200 python3 tools/latency_sweep.py
 run 200 python3 tools/rx_latency.py 1 64
 run 200 python3 tools/block_latency.py
+run 200 python3 tools/live_latency.py
 run 200 python3 tools/decode_sweep.py
 run 200 python3 tools/parity_sweep.py
 run 200 python3 tools/detect_sweep.py
