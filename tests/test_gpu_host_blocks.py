@@ -654,7 +654,7 @@ def test_instance_and_empty_run_of_every_block_kind(pkg):
             assert b.msgs == [] and all(len(b.output(p)) == 0 for p in range(n_out))
 
 
-@pytest.mark.parametrize("chunk,batch", [(4096, 1000), (777, 2)])
+@pytest.mark.parametrize("chunk,batch", [(4096, 1000), (777, 2), (2000, 0)])   # 0: no batch size, the reference's timing
 def test_pump_chain_of_three_blocks(tmp_path, oracle, chunk, batch):
     """The command-line scheduler joins signal -> demod -> decode by buffers of `chunk` items (C++ only, no Python
     between the blocks): same messages as the fused block."""
@@ -698,7 +698,7 @@ def test_decode_block_debug_counters_in_the_references_wording(tmp_path, oracle)
     assert int(lines[-1].split("total:")[1].split(",")[0]) == total
 
 
-@pytest.mark.parametrize("n_rx,chunk,batch", [(1, 4096, 1000), (1, 777, 2), (2, 1500, 3)])
+@pytest.mark.parametrize("n_rx,chunk,batch", [(1, 4096, 1000), (1, 777, 2), (2, 1500, 3), (1, 3000, 0), (2, 900, 0)])
 def test_streaming_abi_from_plain_c(tmp_path, oracle, n_rx, chunk, batch):
     """signal -> demod -> decode through gr80211_block_work_out / gr80211_block_work from a C program (tags as
     records, vector values copied between blocks): same messages as the model of the reference's chain."""
@@ -714,7 +714,7 @@ def test_streaming_abi_from_plain_c(tmp_path, oracle, n_rx, chunk, batch):
     assert stat == "STAT pdus=%d" % len(want)
 
 
-@pytest.mark.parametrize("n_rx,chunk,batch", [(1, 3000, 7), (1, 777, 2), (1, 65536, 1000), (2, 1500, 3)])
+@pytest.mark.parametrize("n_rx,chunk,batch", [(1, 3000, 7), (1, 777, 2), (1, 65536, 1000), (2, 1500, 3), (1, 2500, 0), (2, 4096, 0)])
 def test_pump_chain_on_three_threads_equals_one_thread(pkg, tmp_path, oracle, n_rx, chunk, batch):
     """gr80211_pump chaint (signal, demod and decode on a thread each, ring buffers between them, as GNU Radio's
     scheduler runs a flowgraph) publishes the messages of gr80211_pump chain (the same blocks called in turn) and of
