@@ -166,3 +166,54 @@ def test_large_batch_decoder_leaves_register_room(pkg, tmp_path):
     gran = 8  # registers are handed out in blocks of eight
     up = lambda v: (v + gran - 1) // gran * gran
     assert 2 * up(lean[0]) + up(demod[0]) <= 512 and 2 * up(lean[0]) + up(pre[0]) <= 512, (lean, demod, pre)
+
+
+def test_lane_state_decoder_leaves_its_look_ahead_registers_alone(pkg, tmp_path):
+    """The one-wave-per-frame decoder brings soft bits into L2 with loads issued from inline assembly, which the
+    compiler does not count: nothing may write such a load's destination register before the wait that follows it, or
+    the late arrival would overwrite a live value.  Read from the code object the library carries: every single-dword
+    global load without a scalar base in that kernel, up to the next full wait for vector memory in
+    program order (the loads inside the loops are waited for in the same basic block)."""
+    import shutil
+    import subprocess
+    tools = "/opt/rocm/lib/llvm/bin"
+    if not os.path.exists(os.path.join(tools, "llvm-objdump")):
+        import pytest
+        pytest.skip("no llvm-objdump on this machine")
+    so = tmp_path / "lib.so"
+    shutil.copy(pkg.rx.LIB_PATH, so)
+    subprocess.run([os.path.join(tools, "llvm-objdump"), "--offloading", str(so)], check=True, capture_output=True, cwd=tmp_path)
+    text = ""
+    for f in sorted(tmp_path.glob("lib.so.*gfx950*")):
+        text += subprocess.run([os.path.join(tools, "llvm-objdump"), "-d", str(f)], capture_output=True, text=True).stdout
+    m = re.search(r"^[0-9a-f]+ <(\S*k_decode_lane_state\S*)>:\n(.*?)(?=^[0-9a-f]+ <|\Z)", text, flags=re.S | re.M)
+    assert m, "kernel not found in the code object"
+    ins = [l.split("//")[0].strip() for l in m.group(2).split("\n")]
+    ins = [l for l in ins if l and not l.endswith(":")]
+
+    def written(line):
+        op, _, rest = line.partition(" ")
+        if op.startswith(("global_store", "buffer_store", "ds_write", "v_cmp", "s_", "v_readlane", "v_readfirstlane")):
+            return set()
+        dst = rest.split(",")[0].strip()
+        regs = set()
+        a = re.fullmatch(r"v(\d+)", dst)
+        b = re.fullmatch(r"v\[(\d+):(\d+)\]", dst)
+        if a:
+            regs = {int(a.group(1))}
+        if b:
+            regs = set(range(int(b.group(1)), int(b.group(2)) + 1))
+        if op.startswith(("v_permlane16_swap", "v_permlane32_swap", "v_swap")):
+            regs |= {int(x) for x in re.findall(r"\bv(\d+)\b", rest)}
+        return regs
+
+    loads = [i for i, l in enumerate(ins) if re.match(r"global_load_dword v\d+, v\[\d+:\d+\], off", l)]
+    assert len(loads) >= 12, loads      # four code rates: one before the loops, one in each of the two loops
+    for i in loads:
+        reg = int(re.match(r"global_load_dword v(\d+),", ins[i]).group(1))
+        j = i + 1
+        while j < len(ins) and not ins[j].startswith("s_waitcnt vmcnt(0)"):
+            assert reg not in written(ins[j]), (ins[i], ins[j])
+            assert not ins[j].startswith("s_endpgm"), (ins[i], "no wait before the code ends")
+            j += 1
+        assert j < len(ins)
