@@ -400,6 +400,18 @@ def test_streaming_abi_mu_option_and_errors(pkg, oracle):
             b.set_option(stream.OPT_MU_POS, 1)
         with pytest.raises(RuntimeError):
             b.work([np.zeros(8, np.float32)], [(0, 3, "format", 0)])
+        b.set_option(stream.OPT_MAX_HOLD, 100000)
+        b.set_option(stream.OPT_FINISH_IN_CALL, 1)
+    with stream.StreamBlock(stream.RX, 4) as b:
+        b.set_option(stream.OPT_MAX_HOLD, 500000)
+        with pytest.raises(RuntimeError):
+            b.set_option(stream.OPT_FINISH_IN_CALL, 1)   # a block that reads the antenna stream never waits in a call
+        with pytest.raises(RuntimeError):
+            b.set_option(stream.OPT_MAX_HOLD, 0)
+    with stream.StreamBlock(stream.DEMOD, 4) as b:
+        b.set_option(stream.OPT_FINISH_IN_CALL, 0)
+        with pytest.raises(RuntimeError):
+            b.set_option(stream.OPT_MAX_HOLD, 100000)      # demod's rounds are cut by frames alone
     with pytest.raises(RuntimeError):
         stream.StreamBlock(17)
 
