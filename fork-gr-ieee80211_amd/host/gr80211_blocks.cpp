@@ -1091,9 +1091,11 @@ int decode::general_work(int, gr_vector_int &ninput_items, gr_vector_const_void_
     if (!send(in, span, n)) return 0;
     log.set_enqueued(r0 + (uint64_t)n);
     if (d_finish) {
-        // what this call completed is decoded and published before it returns
+        // what this call completed is decoded and published before it returns -- unless the window ends inside a
+        // packet: then the next call is certain and near, and rounds on their way need not hold this one up (which is
+        // what keeps a stream played at full speed moving: its windows end anywhere)
         if (d_state != S_COLLECT && !d_fill->desc.empty() && !cut()) return 0;
-        if (!d_flight.empty() && !advance(true, true)) return 0;
+        if (!d_flight.empty() && !advance(d_state != S_COLLECT, d_state != S_COLLECT)) return 0;
     }
     consume_each((int)(log.settled(r0) - r0));
     return 0;
@@ -1990,8 +1992,12 @@ int demod::general_work(int noutput_items, gr_vector_int &ninput_items, gr_vecto
                 continue;
             }
             if (d_finish && !r.desc.empty() && d.nsamp > n - used) {
-                // this frame ends in a later call: the ones before it do not wait for it (the item is looked at again)
-                if (!cut()) {
+                // this frame ends in a later call: the ones before it do not wait for it (the item is looked at again),
+                // nor does the call wait for them -- the next one is certain and near
+                d_cutAhead = true;
+                const bool ok = cut();
+                d_cutAhead = false;
+                if (!ok) {
                     consume_each(used);
                     return 0;
                 }
@@ -2037,7 +2043,7 @@ int demod::general_work(int noutput_items, gr_vector_int &ninput_items, gr_vecto
         // what this call completed is demodulated before it returns (the 320 items passed over after a frame carry
         // nothing: the frame is complete with its last sample)
         if (d_fill && d_state != S_COLLECT && !d_fill->desc.empty() && !cut()) return 0;
-        if (!d_flight.empty() && !harvest(true)) return 0;
+        if (!d_flight.empty() && !harvest(d_state != S_COLLECT)) return 0;
     }
     n = ninput_items[0];
     if (output_items.empty()) return 0;
@@ -2268,7 +2274,7 @@ bool demod::cut()
     d_flight.push_back(&r);
     if (r.worker.joinable()) r.worker.join();
     // a round the call is going to wait for anyway runs on the caller's thread: starting one costs as much as the round
-    if (d_finish) run(r);
+    if (d_finish && d_state != S_COLLECT && !d_cutAhead) run(r);
     else r.worker = std::thread([this, &r] { run(r); });
     return true;
 }

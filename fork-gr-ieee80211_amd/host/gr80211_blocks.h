@@ -638,6 +638,7 @@ private:
     round *free_round();
     int d_nrx, d_muPos, d_batch, d_device;
     bool d_finish = false;
+    bool d_cutAhead = false;                // the round being cut is not waited for by this call
     // Three rounds to begin with (one filling, two on their way); more are made when the soft bits of finished rounds
     // leave slowly (small output buffers), up to MAX_ROUNDS, so that input is only refused for lack of output room.
     static constexpr int N_ROUNDS = 3, MAX_ROUNDS = 16;
