@@ -1036,8 +1036,9 @@ int decode::general_work(int, gr_vector_int &ninput_items, gr_vector_const_void_
                 d_nPdu++;
             } else {
                 d_state = S_COLLECT;
-                if (d_finish && !d_fill->desc.empty() && t_nTotal > (long)(n - used)) {
-                    // this packet ends in a later call: the ones before it do not wait for it
+                if (d_finish && !d_fill->desc.empty() && t_nTotal > (long)(n - used) && d_flight.size() < 2) {
+                    // this packet ends in a later call: the ones before it do not wait for it (while two rounds are on
+                    // their way they do wait, for company: a stream that comes faster than rounds return gets larger rounds)
                     if (!send(in, span, used)) return 0;
                     span = used;
                     if (!cut()) return 0;
@@ -1256,9 +1257,10 @@ const size_t MAX_SPAN = 224 + 80 * ((4095 * 8 + 22 + 23) / 24);
 rx::sptr rx::make(int n_rx, int batch_frames, int device) { return sptr(new rx(n_rx, batch_frames, device)); }
 
 rx::rx(int n_rx, int batch_frames, int device, int n_out, bool sync_port)
-    : block((n_rx == 2 ? 2 : 1) + (sync_port ? 1 : 0), n_out), d_nrx(n_rx == 2 ? 2 : 1), d_batch(batch_frames < 1 ? 1 : batch_frames),
+    : block((n_rx == 2 ? 2 : 1) + (sync_port ? 1 : 0), n_out), d_nrx(n_rx == 2 ? 2 : 1), d_batch(batch_frames < 1 ? 4096 : batch_frames),
       d_port0(sync_port ? 1 : 0), d_up(device), d_maxHold((size_t)1 << 24)
 {
+    d_adaptive = batch_frames < 1;
     if (!d_up.ok()) {
         d_err = "gr80211_create failed";
         return;
@@ -1438,10 +1440,18 @@ int rx::take_input(gr_vector_int &ninput_items, gr_vector_const_void_star &input
         sw_up.reset();
         if (!scan_first) scan();
         log.set_enqueued(r0 + (uint64_t)n);
+    }
+    {
         // a round is cut when enough sync bytes are pending (the frame a round carried over counts once its samples
         // have come in), or when it holds as many samples as it may
+        round &f = *d_fill;
         const uint64_t end = f.base + f.n;
-        const bool enough = f.trig.size() >= (size_t)d_batch && (f.n_new > 0 || (d_wantEnd && end >= d_wantEnd));
+        // Made without a batch size, the block sizes its rounds by the traffic: a frame goes at once while fewer than two
+        // rounds are on their way (a quiet channel: nothing ever waits for company), and what arrives while two are
+        // goes together in the next one (a busy channel, or a recording played at full speed: rounds of hundreds) --
+        // looked at in every call, also one that brings nothing new, since it is a round's return that lets it go.
+        const size_t want = d_adaptive && d_flight.size() < 2 ? 1 : (size_t)d_batch;
+        const bool enough = f.trig.size() >= want && (f.n_new > 0 || (d_wantEnd && end >= d_wantEnd));
         if (f.n > 0 && (enough || f.n >= d_maxHold)) {
             stopwatch sw_cut(d_tCut, d_profile ? "cut" : nullptr);
             if (!cut(false)) return -1;
@@ -1985,15 +1995,19 @@ int demod::general_work(int noutput_items, gr_vector_int &ninput_items, gr_vecto
             d.mu_pos = (uint32_t)d_muPos;
             const tag_t *ch = tag_find(tags, "chan");
             const bool usable = !(d.nsamp < 0 || d.nsamp > (1 << 24) || !ch || ch->cvec.size() < 64);
-            if (!(usable && d_finish && !r.desc.empty() && d.nsamp > n - used)) d_nSeen++;  // (else looked at again below)
+            int running = 0;
+            for (const round *q : d_flight) running += q->state.load() == R_RUN;
+            const bool cut_ahead = usable && d_finish && !r.desc.empty() && d.nsamp > n - used && running < 2;
+            if (!cut_ahead) d_nSeen++;  // (else the item is looked at again below)
             if (!usable) {
                 // nothing a frame can be taken from: pass over this item and look for the next tagged one
                 used++;
                 continue;
             }
-            if (d_finish && !r.desc.empty() && d.nsamp > n - used) {
+            if (cut_ahead) {
                 // this frame ends in a later call: the ones before it do not wait for it (the item is looked at again),
-                // nor does the call wait for them -- the next one is certain and near
+                // nor does the call wait for them -- the next one is certain and near.  (While two rounds are running
+                // they do wait, for company: a stream that comes faster than rounds return gets larger rounds.)
                 d_cutAhead = true;
                 const bool ok = cut();
                 d_cutAhead = false;

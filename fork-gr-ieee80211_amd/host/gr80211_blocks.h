@@ -445,7 +445,7 @@ class rx : public block
 public:
     typedef std::shared_ptr<rx> sptr;
     // n_rx = 1: inputs {u8 sync, c64} like ieee80211::signal; n_rx = 2: {u8 sync, c64, c64} like signal2.
-    static sptr make(int n_rx = 1, int batch_frames = 0, int device = 0);  // no batch size: rounds of one frame
+    static sptr make(int n_rx = 1, int batch_frames = 0, int device = 0);  // no batch size: rounds sized by the traffic
     ~rx() override;
 
     void forecast(int noutput_items, gr_vector_int &ninput_items_required) override;
@@ -511,6 +511,7 @@ protected:
     round *free_round();
 
     int d_nrx, d_batch;
+    bool d_adaptive = false;            // rounds sized by the traffic (made without a batch size)
     int d_port0 = 1;                    // input port of the first antenna (1 behind a sync port, else 0)
     size_t d_carryBack = 0;             // samples before a round's end that the next round always gets again
     int d_muPos = 0;
@@ -541,7 +542,7 @@ class signal : public rx
 {
 public:
     typedef std::shared_ptr<signal> sptr;
-    static sptr make(int n_rx = 1, int batch_frames = 0, int device = 0);  // no batch size: rounds of one frame
+    static sptr make(int n_rx = 1, int batch_frames = 0, int device = 0);  // no batch size: rounds sized by the traffic
     void forecast(int noutput_items, gr_vector_int &ninput_items_required) override;
     int general_work(int noutput_items, gr_vector_int &ninput_items, gr_vector_const_void_star &input_items,
                      gr_vector_void_star &output_items) override;

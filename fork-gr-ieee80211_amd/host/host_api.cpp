@@ -39,8 +39,8 @@ gr80211_block *gr80211_block_create(int kind, int batch_frames, int device)
 {
     std::unique_ptr<gr80211_block> h(new gr80211_block());
     h->kind = kind;
-    // no batch size: rounds of one frame, so that a frame never waits for others on a quiet channel
-    const int batch = batch_frames > 0 ? batch_frames : 1;
+    // no batch size: rounds sized by the traffic, so that a frame never waits for others on a quiet channel
+    const int batch = batch_frames > 0 ? batch_frames : 0;
     switch (kind) {
     // decode and demod made without a batch size finish a packet in the call that completes it, as the reference does
     case GR80211_BLOCK_DECODE: h->b = decode::make(false, batch_frames > 0 ? batch_frames : 0, device); h->n_in = 1; break;

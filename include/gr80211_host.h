@@ -94,8 +94,9 @@ typedef void (*gr80211_msg_fn)(void *user, const uint8_t *blob, int len);
 
 /* batch_frames: frames (packets) a round collects before it goes to the GPU -- the knob between latency and rate.
    <= 0, the default, is for live reception: a block made the way the reference makes its own never sits on a frame while
-   the channel is quiet.  RX and SIGNAL then work in rounds of one frame (a message leaves two windows after the
-   frame's last sample), DECODE and DEMOD(2) keep the reference's timing (GR80211_OPT_FINISH_IN_CALL = 1).  A stream
+   the channel is quiet.  RX and SIGNAL then size their rounds by the traffic -- a frame goes at once while fewer than two rounds
+   are on their way, and what arrives while two are goes together in the next (a message leaves two windows after the
+   frame's last sample on a quiet channel; a recording played at full speed gets rounds of hundreds) --, DECODE and DEMOD(2) keep the reference's timing (GR80211_OPT_FINISH_IN_CALL = 1).  A stream
    played at full speed wants thousands (the rates quoted for these blocks are at 4096 and 16 384).  CAPTURE(2) cuts
    its rounds by samples (GR80211_OPT_MAX_HOLD) and ignores this. */
 gr80211_block *gr80211_block_create(int kind, int batch_frames, int device);

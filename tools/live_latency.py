@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """A live receiver's view: a 20-Msamples/s antenna stream with a 1500-byte VHT MCS8 frame every 3 ms, handed over in
 windows of 8192 samples at the pace of the air (one every 0.41 ms), and for every frame the time from the arrival of the
-window that holds its last sample to its message.  Blocks: the fused rx block made without a batch size (rounds of one frame) and with rounds of 4096
+window that holds its last sample to its message.  Blocks: the fused rx block made without a batch size (rounds by the traffic) and with rounds of 4096
 frames (the latter shows what a batch size costs a quiet channel), capture_rx with the shortest rounds it takes (438 016 samples), and signal
 -> demod -> decode as three blocks called in turn, demod and decode made without a batch size."""
 import gc
@@ -86,7 +86,7 @@ def main():
             print("%-58s %d messages in all, %d frames sent" % (name, len(stamps), n_frames))
         report(name, arrive, stamps[:n_live])
 
-    fused(stream.RX, 0, "rx block made without a batch size (rounds of one frame)")
+    fused(stream.RX, 0, "rx block made without a batch size (rounds by the traffic)")
     fused(stream.RX, 4096, "rx block, rounds of 4096 frames")
     fused(stream.CAPTURE, 0, "capture_rx block, rounds of 438016 samples (22 ms)", with_sync=False, hold=438016)
 

@@ -73,8 +73,13 @@ def main():
     only = os.environ.get("GR80211_STREAM_ONLY", "")  # "chain": the three-block rows alone
     for pin in (True, False):
         for chunk, batch in ((8192, 4096), (65536, 4096), (65536, 16384), (1 << 18, 16384), (1 << 20, 16384)):
-            if not only:
+            if not only or only == "rx":
+                batch = int(os.environ.get("GR80211_RX_BATCH", batch))  # frames per round (experiments; 0: made without a batch size)
                 run(["rx", 1, chunk, batch, f_tr, f_iq], ns, "rx      window %7d batch %5d" % (chunk, batch), pin)
+    if only == "rx":
+        for f in (f_iq, f_tr, f_llr, f_tg):
+            os.remove(f)
+        return
     # the reference's three blocks as three blocks: one thread each (a flowgraph), and all on one thread
     n_chain = min(n, int(os.environ.get("GR80211_CHAIN_FRAMES", "200000")))  # frames the three-block rows play
     f_iqc = f_iq
