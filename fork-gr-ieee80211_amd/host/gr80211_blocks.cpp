@@ -1489,6 +1489,7 @@ bool rx::cut(bool final)
         nx->trig.assign(r.trig.begin() + (long)k, r.trig.end());
         nx->n_new = 0;
         nx->n = 0;
+        nx->n_carry = 0;
         nx->base = end;
         if (!nx->trig.empty() || d_carryBack) {
             uint64_t from = nx->trig.empty() ? end : std::max(nx->trig[0].pos, r.base);
@@ -1511,6 +1512,7 @@ bool rx::cut(bool final)
             }
             nx->base = from;
             nx->n = cnt;
+            nx->n_carry = cnt;
         }
         nx->state = round::FILL;
     }
@@ -1662,6 +1664,7 @@ bool rx::flush()
         d_fill->state = round::FILL;
         d_fill->n = 0;
         d_fill->n_new = 0;
+        d_fill->n_carry = 0;
         d_fill->trig.clear();
     }
     return true;
@@ -2421,6 +2424,7 @@ capture_rx::sptr capture_rx::make(int n_rx, int device) { return sptr(new captur
 capture_rx::capture_rx(int n_rx, int device) : rx(n_rx, 1 << 30, device, 0, false)
 {
     d_carryBack = DET_MARGIN + DET_HISTORY;
+    if (const char *e = getenv("GR80211_CAPTURE_MIN_ROUND")) set_min_round((size_t)atoll(e));  // experiments and tests
 }
 
 void capture_rx::forecast(int noutput_items, gr_vector_int &ninput_items_required)
@@ -2466,6 +2470,9 @@ int capture_rx::general_work(int, gr_vector_int &ninput_items, gr_vector_const_v
         if (f.n >= d_maxHold && !cut(false)) return 0;
     }
     log.set_enqueued(r0 + (uint64_t)n);
+    // live reception (set_min_round): a round goes as soon as it holds enough new samples and fewer than two are on their
+    // way -- looked at in every call, since it is a round's return that lets the next one go
+    if (d_minNew && d_fill->n >= d_fill->n_carry + d_minNew && d_flight.size() < 2 && !cut(false)) return 0;
     consume_each((int)(log.settled(r0) - r0));
     return 0;
 }

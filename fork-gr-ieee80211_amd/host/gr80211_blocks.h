@@ -486,6 +486,7 @@ protected:
         uint64_t base = 0;                 // absolute index of item 0
         std::vector<trigger> trig;         // sync bytes inside, in stream order
         size_t n_new = 0;                  // ... of which arrived while this round was filled (the rest were carried over)
+        size_t n_carry = 0;                // samples at the round's start that the round before handed over
         enum { FREE, FILL, PROBE, DECODE } state = FREE;
         bool final = false;
         std::vector<gr80211_frame_desc> pd;  // probe: one per sync byte with its 224 samples
@@ -678,6 +679,10 @@ public:
                      gr_vector_void_star &output_items) override;
     bool flush() override;
     uint64_t sync_bytes_found() const { return d_nSync; }
+    // Live reception: a round may go once it holds this many samples the round before did not (at least 8192) while
+    // fewer than two rounds are on their way, instead of waiting for set_max_hold samples (22 ms of air at least): a
+    // frame's message then follows its last sample by a round's length and the GPU's time.  0, the default: off.
+    void set_min_round(size_t items) { d_minNew = items ? std::max<size_t>(items, 8192) : 0; }
 
 protected:
     bool before_cut(round &r, bool final) override;
@@ -687,6 +692,7 @@ private:
     static constexpr size_t DET_MARGIN = 1024;   // a round leaves the sync bytes of its last samples to the next round
     static constexpr size_t DET_HISTORY = 1024;  // samples the next round gets before the first one it searches
     uint64_t d_detFrom = 0;                      // absolute index from which sync bytes are still to be taken
+    size_t d_minNew = 0;                         // set_min_round
     uint64_t d_nSync = 0;
 };
 

@@ -157,6 +157,11 @@ int gr80211_block_set_option(gr80211_block *b, int option, int value)
         else return -1;
         return 0;
     }
+    if (option == GR80211_OPT_MIN_ROUND) {
+        if (!c || value < 0) return -1;
+        c->set_min_round((size_t)value);
+        return 0;
+    }
     if (option == GR80211_OPT_AMPDU_STRICT) {
         if (d) d->set_ampdu_strict(value != 0);
         if (r) r->set_ampdu_strict(value != 0);

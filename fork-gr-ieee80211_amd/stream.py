@@ -12,7 +12,7 @@ DECODE, RX, RX2, CAPTURE, CAPTURE2, SIGNAL, SIGNAL2, DEMOD, DEMOD2 = range(9)
 TAG_KEYS = ("rad", "snr", "rssi", "format", "len", "total", "cr", "mcs", "ampdu", "trellis", "mu2x1chan",
             "cfo", "seq", "nsamp", "chan", "sssnr0", "sssnr1")
 OUT_DTYPES = {SIGNAL: np.complex64, SIGNAL2: np.complex64, DEMOD: np.float32, DEMOD2: np.float32}
-OPT_MU_POS, OPT_AMPDU_STRICT, OPT_DEBUG, OPT_FINISH_IN_CALL, OPT_MAX_HOLD = 0, 1, 2, 3, 4
+OPT_MU_POS, OPT_AMPDU_STRICT, OPT_DEBUG, OPT_FINISH_IN_CALL, OPT_MAX_HOLD, OPT_MIN_ROUND = 0, 1, 2, 3, 4, 5
 EXPORTS = ("gr80211_block_create", "gr80211_block_destroy", "gr80211_block_set_msg_handler",
            "gr80211_block_set_option", "gr80211_block_n_inputs", "gr80211_block_forecast", "gr80211_block_work",
            "gr80211_block_flush", "gr80211_block_last_error", "gr80211_block_n_outputs", "gr80211_block_work_out",

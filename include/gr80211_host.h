@@ -88,6 +88,9 @@ typedef struct {
                                       DECODE (at least 4096), samples from the first pending sync byte on for RX, SIGNAL and CAPTURE
                                       (at least four times the longest frame, 438 016 samples; CAPTURE cuts its rounds by this
                                       alone).  Bounds the time a frame waits for its round on a channel with little traffic. */
+#define GR80211_OPT_MIN_ROUND 5      /* CAPTURE(2), live reception: a round may go once it holds this many samples the round before did
+                                      not (at least 8192) while fewer than two rounds are on their way, instead of waiting for
+                                      GR80211_OPT_MAX_HOLD samples; 0 (the default): off. */
 
 typedef struct gr80211_block gr80211_block;
 typedef void (*gr80211_msg_fn)(void *user, const uint8_t *blob, int len);

@@ -274,12 +274,13 @@ def test_capture_block_raw_stream(tmp_path, oracle):
     assert "frames=%d " % model_chain.dealt_with in stat + " ", stat
 
 
-@pytest.mark.parametrize("hold", [438016, 700001])
-def test_capture_block_in_rounds_equals_the_whole_capture(tmp_path, pkg, rxctx, hold):
+@pytest.mark.parametrize("hold,min_round", [(438016, 0), (700001, 0), (438016, 8192), (700001, 30000)])
+def test_capture_block_in_rounds_equals_the_whole_capture(tmp_path, pkg, rxctx, hold, min_round):
     """capture_rx cuts a long stream into rounds and finds each round's sync bytes when it cuts it; the messages are
     those of gr80211_rx_capture over the whole stream at once, whatever the round length and the windows (frames of
     mixed formats and lengths with gaps of noise between them, so that round ends fall inside preambles, payloads
-    and gaps alike)."""
+    and gaps alike).  min_round: the rounds of live reception, which go as soon as they hold that many new samples and
+    fewer than two are on their way -- where they end then depends on the GPU's pace, the messages must not."""
     import torch
     tx = pkg.txgen
     rng = np.random.default_rng(71)
@@ -307,7 +308,7 @@ def test_capture_block_in_rounds_equals_the_whole_capture(tmp_path, pkg, rxctx, 
     f0 = tmp_path / "iq0.bin"
     iq0.tofile(f0)
     for chunk in (65536, 7001):
-        got, stat = run_pump(["capture", 1, chunk, f0], env={"GR80211_RX_MAX_HOLD": str(hold)})
+        got, stat = run_pump(["capture", 1, chunk, f0], env={"GR80211_RX_MAX_HOLD": str(hold), "GR80211_CAPTURE_MIN_ROUND": str(min_round)})
         bad = [i for i in range(min(len(got), len(want))) if got[i] != want[i]]
         assert got == want, (chunk, len(got), len(want), bad[:10], [len(got[i]) for i in bad[:5]], [len(want[i]) for i in bad[:5]])
         assert "frames=%d " % nf in stat + " ", stat
@@ -408,6 +409,11 @@ def test_streaming_abi_mu_option_and_errors(pkg, oracle):
             b.set_option(stream.OPT_FINISH_IN_CALL, 1)   # a block that reads the antenna stream never waits in a call
         with pytest.raises(RuntimeError):
             b.set_option(stream.OPT_MAX_HOLD, 0)
+        with pytest.raises(RuntimeError):
+            b.set_option(stream.OPT_MIN_ROUND, 16384)    # rounds by samples are the capture block's
+    with stream.StreamBlock(stream.CAPTURE) as b:
+        b.set_option(stream.OPT_MIN_ROUND, 16384)
+        b.set_option(stream.OPT_MIN_ROUND, 0)
     with stream.StreamBlock(stream.DEMOD, 4) as b:
         b.set_option(stream.OPT_FINISH_IN_CALL, 0)
         with pytest.raises(RuntimeError):

@@ -65,13 +65,15 @@ def main():
             print("%-58s message after the last sample's window: median %.2f ms, min %.2f, max %.2f (%d frames)" %
                   (name, np.median(lat), lat.min(), lat.max(), len(lat)))
 
-    def fused(kind, batch, name, with_sync=True, hold=None):
+    def fused(kind, batch, name, with_sync=True, hold=None, min_round=None):
         with stream.StreamBlock(kind, batch) as b:
             stamps = []
             b._cb = stream.MSG_FN(lambda user, p, n: stamps.append(time.perf_counter()))
             b.lib.gr80211_block_set_msg_handler(b.h, b._cb, None)
             if hold:
                 b.set_option(stream.OPT_MAX_HOLD, hold)
+            if min_round:
+                b.set_option(stream.OPT_MIN_ROUND, min_round)
             held = [0]
 
             def step(at, end):
@@ -89,6 +91,7 @@ def main():
     fused(stream.RX, 0, "rx block made without a batch size (rounds by the traffic)")
     fused(stream.RX, 4096, "rx block, rounds of 4096 frames")
     fused(stream.CAPTURE, 0, "capture_rx block, rounds of 438016 samples (22 ms)", with_sync=False, hold=438016)
+    fused(stream.CAPTURE, 0, "capture_rx block, rounds from 16384 new samples on", with_sync=False, min_round=16384)
 
     # three blocks in turn on one thread: what signal gives goes to demod in the same pass, demod's soft bits to decode
     with stream.StreamBlock(stream.SIGNAL) as sg, stream.StreamBlock(stream.DEMOD) as dm, stream.StreamBlock(stream.DECODE) as dc:

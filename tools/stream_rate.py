@@ -76,7 +76,10 @@ def main():
             if not only or only == "rx":
                 batch = int(os.environ.get("GR80211_RX_BATCH", batch))  # frames per round (experiments; 0: made without a batch size)
                 run(["rx", 1, chunk, batch, f_tr, f_iq], ns, "rx      window %7d batch %5d" % (chunk, batch), pin)
-    if only == "rx":
+    if only == "capture":
+        run(["capture", 1, 65536, f_iq], ns, "capture window   65536")
+        run(["capture", 1, 8192, f_iq], ns, "capture window    8192")
+    if only in ("rx", "capture"):
         for f in (f_iq, f_tr, f_llr, f_tg):
             os.remove(f)
         return
