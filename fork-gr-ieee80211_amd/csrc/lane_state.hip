@@ -28,6 +28,7 @@
 //
 // Then the wave descrambles, assembles and checks the packet: what assemble.h does with one lane per frame, with the
 // frame's words, the CRC-32 of an MPDU and the copy into the PDU slot spread over the 64 lanes.
+#include <cstdlib>
 #include <utility>
 
 #include "acs_common.h"
@@ -262,6 +263,90 @@ __device__ __forceinline__ void ls_forward(cfloatp base, int n, int T, unsigned 
     ls_touched(warm0);
 }
 
+// ---- experiment (GR80211_LS_RING=1): the same forward pass with the soft bits travelling through LDS ---------------
+// Scalar loads can only be waited for all at once, so the look-ahead above is one sub-body and no more, and the scalar
+// registers are full.  Here the wave fetches a block's soft bits with two vector loads two blocks ahead of their use
+// (one soft bit per lane and load), parks them in a ring of four blocks in LDS when the block in between is done, and
+// every sub-body reads its soft bits from there (all lanes the same address: a broadcast); the loads are counted, so
+// nothing of this waits.  Columns past the frame's end repeat its last soft bit, as above.  Bit-exact, a few per cent
+// faster with several waves per SIMD, slower for a lone wave (the LDS reads cost it more issue slots than the waits
+// they remove), so the library does not use it by itself.
+constexpr int LS_RING_BLOCKS = 4;
+constexpr int LS_RING_MAX = LS_RING_BLOCKS * LS_BLOCK * 2;  // rate 1/2 reads two soft bits per step
+
+template <int NC>
+__device__ __forceinline__ void lsr_load(float (&dst)[NC], const float *ring, int q)
+{
+#pragma unroll
+    for (int j = 0; j < NC; j++) dst[j] = ring[q + j];
+}
+
+template <int CR, int SB>
+__device__ __forceinline__ void lsr_sub(float &m, float (&cur)[LsRate<CR>::SUB / Rate<CR>::P * Rate<CR>::COLS], const float *ring, int &rpos,
+                                        const LsCoef &k, uint32_t &plo, uint32_t &phi)
+{
+    constexpr int SUB = LsRate<CR>::SUB, NC = SUB / Rate<CR>::P * Rate<CR>::COLS;
+    constexpr int RING = LS_RING_BLOCKS * (LS_BLOCK / Rate<CR>::P * Rate<CR>::COLS);
+    float nxt[NC];
+    int q = rpos + NC;  // the ring is a whole number of sub-bodies long: a sub-body never wraps
+    q = q >= RING ? q - RING : q;
+    lsr_load<NC>(nxt, ring, q);
+    __builtin_amdgcn_sched_barrier(0);  // the reads set out here, a sub-body ahead, and not where the scheduler would sink them to
+    ls_sub_body<CR, SB>(m, cur, k, plo, phi, std::make_integer_sequence<int, SUB>{});
+#pragma unroll
+    for (int j = 0; j < NC; j++) cur[j] = nxt[j];
+    rpos = q;
+}
+
+template <int CR, int... SB>
+__device__ __forceinline__ void lsr_block(float &m, float (&cur)[LsRate<CR>::SUB / Rate<CR>::P * Rate<CR>::COLS], const float *ring, int &rpos,
+                                          const LsCoef &k, uint32_t &plo, uint32_t &phi, std::integer_sequence<int, SB...>)
+{
+    (lsr_sub<CR, SB>(m, cur, ring, rpos, k, plo, phi), ...);
+}
+
+template <int CR>
+__device__ __forceinline__ void lsr_forward(const float *__restrict__ gl, int n, int T, unsigned long long *__restrict__ w64, int lane,
+                                            float *ring)
+{
+    constexpr int SUB = LsRate<CR>::SUB, NC = SUB / Rate<CR>::P * Rate<CR>::COLS;
+    constexpr int BLOCK_COLS = LS_BLOCK / Rate<CR>::P * Rate<CR>::COLS;  // 72 ... 120: two loads of 64 lanes
+    static_assert(BLOCK_COLS > 64 && BLOCK_COLS <= 128 && BLOCK_COLS % NC == 0 && LS_RING_BLOCKS * BLOCK_COLS <= LS_RING_MAX, "ring layout");
+    LsCoef k;
+    ls_coefficients(lane, k);
+    float m = lane == 0 ? 0.0f : NEG_INIT;
+    uint32_t plo = 0, phi = 0;
+    const int nblk = (T + LS_BLOCK - 1) / LS_BLOCK;
+    const bool second = lane + 64 < BLOCK_COLS;  // lanes that carry a soft bit of the block's second load
+    // blocks 0 and 1 before the first step
+    {
+        const float a0 = gl[ls_clamp(lane, n)], a1 = gl[ls_clamp(64 + lane, n)];
+        const float b0 = gl[ls_clamp(BLOCK_COLS + lane, n)], b1 = gl[ls_clamp(BLOCK_COLS + 64 + lane, n)];
+        ring[lane] = a0;
+        ring[BLOCK_COLS + lane] = b0;
+        if (second) {
+            ring[64 + lane] = a1;
+            ring[BLOCK_COLS + 64 + lane] = b1;
+        }
+    }
+    float cur[NC];
+    int rpos = 0;
+    lsr_load<NC>(cur, ring, 0);
+#pragma unroll 1
+    for (int b = 0; b < nblk; b++) {
+        // block b + 2 sets out now and is parked when this block is done; its place in the ring is neither this block's
+        // nor the next one's, whose first sub-body this block reads ahead
+        const int c2 = (b + 2) * BLOCK_COLS;
+        const float a0 = gl[ls_clamp(c2 + lane, n)], a1 = gl[ls_clamp(c2 + 64 + lane, n)];
+        lsr_block<CR>(m, cur, ring, rpos, k, plo, phi, std::make_integer_sequence<int, LS_BLOCK / SUB>{});
+        const int slot = ((b + 2) % LS_RING_BLOCKS) * BLOCK_COLS;
+        ring[slot + lane] = a0;
+        if (second) ring[slot + 64 + lane] = a1;
+        const int t = b * LS_BLOCK + lane;
+        if (lane < LS_BLOCK && t < T) w64[t] = ((unsigned long long)phi << 32) | plo;
+    }
+}
+
 // One pass of the walk back.  Lane k walks warm + seg steps down from time (k + 1) * seg + warm, starting in lane
 // index l (steps at or past T are skipped, so a lane that starts above the trellis in state 0 arrives at T in state
 // 0); its decoded bits count from time (k + 1) * seg on and leave as whole words.  seen = the lane index it holds at
@@ -485,6 +570,7 @@ __device__ __forceinline__ void ls_assemble(const uint32_t *__restrict__ bits, u
     }
 }
 
+template <bool RING>
 __global__ __launch_bounds__(64 * LS_WAVES) void k_decode_lane_state(
     const float *__restrict__ llr, const gr80211_frame_info *__restrict__ info, const int32_t *__restrict__ slot_frame,
     const GroupInfo *__restrict__ groups, int n_groups, uint32_t *__restrict__ dec, uint32_t *__restrict__ bitsw,
@@ -493,6 +579,7 @@ __global__ __launch_bounds__(64 * LS_WAVES) void k_decode_lane_state(
 {
     __shared__ uint32_t s_crc[256];
     __shared__ uint32_t s_dw[LS_WAVES][LS_DW];
+    __shared__ float s_ring[RING ? LS_WAVES : 1][RING ? LS_RING_MAX : 1];
     {
         uint32_t c = threadIdx.x & 255u;
         for (int i = 0; i < 8; i++) c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
@@ -519,11 +606,21 @@ __global__ __launch_bounds__(64 * LS_WAVES) void k_decode_lane_state(
     unsigned long long *w64 = reinterpret_cast<unsigned long long *>(dec + gi.dec_off) + (size_t)sl * steps;
     uint32_t *bits = bitsw + gi.bits_off + (size_t)sl * words;
     const cfloatp base = (cfloatp)(unsigned long long)(llr + off);
-    switch (__builtin_amdgcn_readfirstlane(gi.cr)) {
-    case CR_12: ls_forward<CR_12>(base, n, T, w64, lane); break;
-    case CR_23: ls_forward<CR_23>(base, n, T, w64, lane); break;
-    case CR_34: ls_forward<CR_34>(base, n, T, w64, lane); break;
-    default: ls_forward<CR_56>(base, n, T, w64, lane); break;
+    if constexpr (RING) {
+        const float *gl = llr + off;
+        switch (__builtin_amdgcn_readfirstlane(gi.cr)) {
+        case CR_12: lsr_forward<CR_12>(gl, n, T, w64, lane, s_ring[wv]); break;
+        case CR_23: lsr_forward<CR_23>(gl, n, T, w64, lane, s_ring[wv]); break;
+        case CR_34: lsr_forward<CR_34>(gl, n, T, w64, lane, s_ring[wv]); break;
+        default: lsr_forward<CR_56>(gl, n, T, w64, lane, s_ring[wv]); break;
+        }
+    } else {
+        switch (__builtin_amdgcn_readfirstlane(gi.cr)) {
+        case CR_12: ls_forward<CR_12>(base, n, T, w64, lane); break;
+        case CR_23: ls_forward<CR_23>(base, n, T, w64, lane); break;
+        case CR_34: ls_forward<CR_34>(base, n, T, w64, lane); break;
+        default: ls_forward<CR_56>(base, n, T, w64, lane); break;
+        }
     }
     // the walk reads survivor words other lanes of this wave stored: they have reached memory when the counter is zero
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -556,8 +653,13 @@ void launch_decode_lane_state(const float *llr, const gr80211_frame_info *info, 
                               int32_t *n_pdu, uint8_t *bits_out, int bits_stride, int strict, const SchedTotals *totals, hipStream_t s)
 {
     const int waves = n_groups * 64;
-    hipLaunchKernelGGL(k_decode_lane_state, dim3((waves + LS_WAVES - 1) / LS_WAVES), dim3(64 * LS_WAVES), 0, s, llr, info, slot_frame,
-                       groups, n_groups, dec, bitsw, out, out_stride, out_len, n_pdu, bits_out, bits_stride, strict, totals);
+    const char *e = getenv("GR80211_LS_RING");  // experiment: soft bits through LDS (read per launch, so that a test can turn it on and off)
+    if (e && e[0] == '1')
+        hipLaunchKernelGGL(k_decode_lane_state<true>, dim3((waves + LS_WAVES - 1) / LS_WAVES), dim3(64 * LS_WAVES), 0, s, llr, info, slot_frame,
+                           groups, n_groups, dec, bitsw, out, out_stride, out_len, n_pdu, bits_out, bits_stride, strict, totals);
+    else
+        hipLaunchKernelGGL(k_decode_lane_state<false>, dim3((waves + LS_WAVES - 1) / LS_WAVES), dim3(64 * LS_WAVES), 0, s, llr, info, slot_frame,
+                           groups, n_groups, dec, bitsw, out, out_stride, out_len, n_pdu, bits_out, bits_stride, strict, totals);
 }
 
 }  // namespace gr80211

@@ -251,6 +251,24 @@ def test_group_widths_agree_bit_for_bit(pkg, ctx_by_waves):
         assert np.array_equal(got[1][0][valid], got[w][0][valid]), w
 
 
+def test_soft_bits_through_lds_experiment_is_bit_exact(pkg, ctx_by_waves, oracle):
+    """GR80211_LS_RING=1: the one-wave-per-frame decoder with its soft bits fetched by vector loads and read from a
+    ring in LDS instead of scalar loads (an experiment the design notes quote; the library does not use it by itself).
+    Same frames as test_each_group_width_against_oracle, same answer: the oracle's."""
+    import os
+    tx = pkg.txgen
+    rng = np.random.default_rng(17)
+    frames = []
+    for k in range(200):
+        frames.append(coded_frame(tx, rng, (0, 1, 2)[k % 3], k % 4, int(rng.integers(20, 520)), mcs=k % 8, snr_scale=1.5, noise=1.2,
+                                  integer=(k % 2 == 0)))
+    os.environ["GR80211_LS_RING"] = "1"
+    try:
+        run_and_compare(pkg, ctx_by_waves[64], oracle, frames)
+    finally:
+        os.environ.pop("GR80211_LS_RING", None)
+
+
 def test_small_batch_form_is_the_callers_choice(pkg):
     """gr80211_set_lane_state_max moves the batch size up to which the one-frame-per-wave decoder is taken: the same
     small batch with the default, with the form switched off and with the default again gives the same bytes."""
