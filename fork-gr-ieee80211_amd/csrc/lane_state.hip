@@ -263,15 +263,16 @@ __device__ __forceinline__ void ls_forward(cfloatp base, int n, int T, unsigned 
     ls_touched(warm0);
 }
 
-// ---- experiment (GR80211_LS_RING=1): the same forward pass with the soft bits travelling through LDS ---------------
+// ---- the same forward pass with the soft bits travelling through LDS (batches of about 3000 frames and more) -------
 // Scalar loads can only be waited for all at once, so the look-ahead above is one sub-body and no more, and the scalar
 // registers are full.  Here the wave fetches a block's soft bits with two vector loads two blocks ahead of their use
 // (one soft bit per lane and load), parks them in a ring of four blocks in LDS when the block in between is done, and
 // every sub-body reads its soft bits from there (all lanes the same address: a broadcast); the loads are counted, so
-// nothing of this waits.  Columns past the frame's end repeat its last soft bit, as above.  Bit-exact, a few per cent
-// faster with several waves per SIMD, slower for a lone wave (the LDS reads cost it more issue slots than the waits
-// they remove), so the library does not use it by itself.
+// nothing of this waits.  Columns past the frame's end repeat its last soft bit, as above.  A few per cent faster with
+// several waves per SIMD, slower for a lone wave (the LDS reads cost it more issue slots than the waits they remove):
+// the launcher takes it from LS_RING_FROM_GROUPS groups on.
 constexpr int LS_RING_BLOCKS = 4;
+constexpr int LS_RING_FROM_GROUPS = 48;  // batches of about 3000 frames and more take this form
 constexpr int LS_RING_MAX = LS_RING_BLOCKS * LS_BLOCK * 2;  // rate 1/2 reads two soft bits per step
 
 template <int NC>
@@ -653,8 +654,11 @@ void launch_decode_lane_state(const float *llr, const gr80211_frame_info *info, 
                               int32_t *n_pdu, uint8_t *bits_out, int bits_stride, int strict, const SchedTotals *totals, hipStream_t s)
 {
     const int waves = n_groups * 64;
-    const char *e = getenv("GR80211_LS_RING");  // experiment: soft bits through LDS (read per launch, so that a test can turn it on and off)
-    if (e && e[0] == '1')
+    // Soft bits through LDS pay from a few waves per SIMD on (measured: level at 2000 frames, 2-5 % faster from 4000 on,
+    // 20 % slower for a lone wave); GR80211_LS_RING=1 / 0 forces the form (read per launch, so that a test can switch it).
+    const char *e = getenv("GR80211_LS_RING");
+    const bool ring = e && (e[0] == '0' || e[0] == '1') ? e[0] == '1' : n_groups >= LS_RING_FROM_GROUPS;
+    if (ring)
         hipLaunchKernelGGL(k_decode_lane_state<true>, dim3((waves + LS_WAVES - 1) / LS_WAVES), dim3(64 * LS_WAVES), 0, s, llr, info, slot_frame,
                            groups, n_groups, dec, bitsw, out, out_stride, out_len, n_pdu, bits_out, bits_stride, strict, totals);
     else

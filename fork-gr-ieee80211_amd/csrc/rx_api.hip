@@ -102,8 +102,8 @@ struct gr80211_ctx {
                                 // wavefront per frame (lane = trellis state)
     bool axis_llr = false;      // GR80211_AXIS_LLR=1 (experiment): the demodulator leaves one value per constellation axis, the
                                 // one-wave decoder folds the soft bits out of it; batches of one modulation per group only
-    int lane_state_max = 14000;
-    int lane_state_default = 14000;  // what gr80211_set_lane_state_max(-1) goes back to (GR80211_LANE_STATE_MAX)  // batches of at most this many frames take the one-wavefront-per-frame form
+    int lane_state_max = 18000;
+    int lane_state_default = 18000;  // what gr80211_set_lane_state_max(-1) goes back to (GR80211_LANE_STATE_MAX)  // batches of at most this many frames take the one-wavefront-per-frame form
                                 // (GR80211_LANE_STATE_MAX; 0 switches the form off)
     hipEvent_t ev[7] = {};
     float ms[6] = {};

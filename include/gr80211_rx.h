@@ -295,7 +295,7 @@ int gr80211_set_ampdu_strict(gr80211_ctx *ctx, int on);
  * one trellis state per lane (k_decode_lane_state): the whole chip works on the batch at once, which is the shortest
  * way to its results when it runs alone (4000 VHT MCS8 frames of 1500 bytes: 1.1 ms against 3.4 ms), at 1.3 times the
  * vector instructions per frame of the forms that put a frame in a lane.  A caller that keeps several batches in
- * flight and is after their combined rate sets 0; max_frames < 0 goes back to the default (14 000, or
+ * flight and is after their combined rate sets 0; max_frames < 0 goes back to the default (18 000, or
  * GR80211_LANE_STATE_MAX).  All forms decode the same bits (lib/decode_impl.cc:237-302).  No counterpart in the
  * reference, whose decoder has one form.
  */
