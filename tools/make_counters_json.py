@@ -12,8 +12,8 @@ import os
 import re
 import sys
 
-# (the counter summaries cut kernel names at 50 characters: k_decode_lane_stat)
-KERNELS = {"k_decode": "k_decode(?:_lean|_split2|_lane_stat[e]?)?", "k_demod": "k_demod", "k_preamble": "k_preamble", "k_viterbi_split": "k_viterbi_split",
+# (the counter summaries cut kernel names at 50 characters: k_decode_lane_stat, or k_decode_lane behind "void ")
+KERNELS = {"k_decode": "k_decode(?:_lean|_split2|_lane(?:_stat[e]?)?)?", "k_demod": "k_demod", "k_preamble": "k_preamble", "k_viterbi_split": "k_viterbi_split",
            "k_traceback": "k_traceback", "k_det_ac": "k_det_ac"}
 
 
